@@ -1,0 +1,75 @@
+// conv_api.hip — C-ABI entry points of the convolution family and dispatch between the generic direct
+// kernels (conv_direct.hip) and the MFMA implicit-GEMM kernels for the hot shapes (conv_mfma.hip).
+#include "dasr_common.h"
+#include "conv_kernels.h"
+
+static int check_geom(const ConvGeom& g) {
+    if (g.B <= 0 || g.H <= 0 || g.W <= 0 || g.Cin <= 0 || g.Ho <= 0 || g.Wo <= 0 || g.Cout <= 0 || g.KH <= 0 ||
+        g.KW <= 0 || g.stride <= 0 || g.pad < 0)
+        return DASR_E_SHAPE;
+    int eh, ew;
+    if (!g.transposed) {
+        eh = (g.H + 2 * g.pad - g.KH) / g.stride + 1;
+        ew = (g.W + 2 * g.pad - g.KW) / g.stride + 1;
+    } else {
+        eh = (g.H - 1) * g.stride - 2 * g.pad + g.KH;
+        ew = (g.W - 1) * g.stride - 2 * g.pad + g.KW;
+    }
+    if (eh != g.Ho || ew != g.Wo) return DASR_E_SHAPE;
+    return DASR_OK;
+}
+
+extern "C" int dasr_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                               int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                               int pad, int transposed, int act, int ps_r, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(w); DASR_CHECK_PTR(y);
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
+    if (ps_r < 1) ps_r = 1;
+    if (ps_r > 1 && (Cout % (ps_r * ps_r)) != 0) return DASR_E_SHAPE;
+    return conv_direct_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
+}
+
+extern "C" int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, int B, int Ho, int Wo, int Cout,
+                                        int act, int ps_r, void* stream) {
+    DASR_CHECK_PTR(dy); DASR_CHECK_PTR(y); DASR_CHECK_PTR(dconv);
+    DASR_CHECK_SHAPE(B > 0 && Ho > 0 && Wo > 0 && Cout > 0);
+    if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
+    if (ps_r < 1) ps_r = 1;
+    if (ps_r > 1 && (Cout % (ps_r * ps_r)) != 0) return DASR_E_SHAPE;
+    ConvGeom g{B, Ho, Wo, 1, Ho, Wo, Cout, 1, 1, 1, 0, 0};
+    return conv_epilogue_bwd(g, dy, y, dconv, act, ps_r, stream);
+}
+
+extern "C" int dasr_conv2d_dgrad(const float* dconv, const float* w, float* dx, int accumulate, int B, int H, int W,
+                                 int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                                 int transposed, void* stream) {
+    DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(w); DASR_CHECK_PTR(dx);
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    int rc = check_geom(g);
+    if (rc) return rc;
+    return conv_direct_dgrad(g, dconv, w, dx, accumulate, stream);
+}
+
+extern "C" size_t dasr_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                              int stride, int pad, int transposed) {
+    (void)B; (void)H; (void)W; (void)Cin; (void)Ho; (void)Wo; (void)Cout; (void)KH; (void)KW; (void)stride; (void)pad;
+    (void)transposed;
+    return 0;
+}
+
+extern "C" int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
+                                 size_t workspace_bytes, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
+                                 int KW, int stride, int pad, int transposed, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(dw);
+    (void)workspace; (void)workspace_bytes;
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    int rc = check_geom(g);
+    if (rc) return rc;
+    rc = conv_direct_wgrad(g, x, dconv, dw, stream);
+    if (rc) return rc;
+    if (dbias) rc = conv_colsum(dconv, dbias, (size_t)B * Ho * Wo, Cout, stream);
+    return rc;
+}

@@ -1,0 +1,196 @@
+// conv_direct.hip — generic direct convolution (any kernel size / stride / ConvTranspose geometry /
+// channel count), NHWC x HWIO, fp32 on the vector ALU.  This is the fall-back for the shapes the MFMA
+// implicit-GEMM kernels (conv_mfma.hip) do not cover: the strided / transposed encoder layers, the
+// 1- and 3-channel inputs, and odd channel counts.  dasr_conv2d_* in conv_api.hip dispatch between them.
+#include "dasr_common.h"
+#include "conv_kernels.h"
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ void __launch_bounds__(256) k_conv_direct_fwd(ConvGeom g, const float* __restrict__ x,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         const float* __restrict__ residual, float* __restrict__ y,
+                                                         int act, int ps_r) {
+    size_t n = (size_t)g.B * g.Ho * g.Wo * g.Cout;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        int co = (int)(idx % g.Cout);
+        size_t pix = idx / g.Cout;
+        int ox = (int)(pix % g.Wo), oy = (int)((pix / g.Wo) % g.Ho), b = (int)(pix / ((size_t)g.Wo * g.Ho));
+        float acc = bias ? bias[co] : 0.f;
+        for (int kh = 0; kh < g.KH; ++kh) {
+            int iy;
+            if (!g.transposed) {
+                iy = oy * g.stride - g.pad + kh;
+            } else {
+                int ty = oy + g.pad - kh;
+                if (ty < 0 || (ty % g.stride) != 0) continue;
+                iy = ty / g.stride;
+            }
+            if (iy < 0 || iy >= g.H) continue;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                int ix;
+                if (!g.transposed) {
+                    ix = ox * g.stride - g.pad + kw;
+                } else {
+                    int tx = ox + g.pad - kw;
+                    if (tx < 0 || (tx % g.stride) != 0) continue;
+                    ix = tx / g.stride;
+                }
+                if (ix < 0 || ix >= g.W) continue;
+                const float* xp = x + (((size_t)b * g.H + iy) * g.W + ix) * g.Cin;
+                const float* wp = w + ((size_t)(kh * g.KW + kw) * g.Cin) * g.Cout + co;
+                for (int ci = 0; ci < g.Cin; ++ci) acc = fmaf(xp[ci], wp[(size_t)ci * g.Cout], acc);
+            }
+        }
+        if (residual) acc += residual[idx];
+        acc = dasr_act(acc, act);
+        y[conv_out_index(g, b, oy, ox, co, ps_r)] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_conv_epilogue_bwd(ConvGeom g, const float* __restrict__ dy,
+                                                           const float* __restrict__ y, float* __restrict__ dconv,
+                                                           int act, int ps_r) {
+    size_t n = (size_t)g.B * g.Ho * g.Wo * g.Cout;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        int co = (int)(idx % g.Cout);
+        size_t pix = idx / g.Cout;
+        int ox = (int)(pix % g.Wo), oy = (int)((pix / g.Wo) % g.Ho), b = (int)(pix / ((size_t)g.Wo * g.Ho));
+        size_t o = conv_out_index(g, b, oy, ox, co, ps_r);
+        dconv[idx] = dy[o] * dasr_act_grad_from_out(y[o], act);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dgrad
+__global__ void __launch_bounds__(256) k_conv_direct_dgrad(ConvGeom g, const float* __restrict__ dconv,
+                                                           const float* __restrict__ w, float* __restrict__ dx,
+                                                           int accumulate) {
+    size_t n = (size_t)g.B * g.H * g.W * g.Cin;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        int ci = (int)(idx % g.Cin);
+        size_t pix = idx / g.Cin;
+        int ix = (int)(pix % g.W), iy = (int)((pix / g.W) % g.H), b = (int)(pix / ((size_t)g.W * g.H));
+        float acc = 0.f;
+        for (int kh = 0; kh < g.KH; ++kh) {
+            int oy;
+            if (!g.transposed) {
+                int ty = iy + g.pad - kh;
+                if (ty < 0 || (ty % g.stride) != 0) continue;
+                oy = ty / g.stride;
+            } else {
+                oy = iy * g.stride - g.pad + kh;
+            }
+            if (oy < 0 || oy >= g.Ho) continue;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                int ox;
+                if (!g.transposed) {
+                    int tx = ix + g.pad - kw;
+                    if (tx < 0 || (tx % g.stride) != 0) continue;
+                    ox = tx / g.stride;
+                } else {
+                    ox = ix * g.stride - g.pad + kw;
+                }
+                if (ox < 0 || ox >= g.Wo) continue;
+                const float* dp = dconv + (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.Cout;
+                const float* wp = w + ((size_t)(kh * g.KW + kw) * g.Cin + ci) * g.Cout;
+                for (int co = 0; co < g.Cout; ++co) acc = fmaf(dp[co], wp[co], acc);
+            }
+        }
+        dx[idx] = accumulate ? dx[idx] + acc : acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// One thread per (tap, ci, co); blockIdx.y splits the output pixels; partial sums go to dw with float atomics
+// (dw zeroed by the caller's hipMemsetAsync).
+__global__ void __launch_bounds__(256) k_conv_direct_wgrad(ConvGeom g, const float* __restrict__ x,
+                                                           const float* __restrict__ dconv, float* __restrict__ dw,
+                                                           size_t pix_per_split) {
+    size_t nW = (size_t)g.KH * g.KW * g.Cin * g.Cout;
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nW) return;
+    int co = (int)(e % g.Cout);
+    int ci = (int)((e / g.Cout) % g.Cin);
+    int tap = (int)(e / ((size_t)g.Cout * g.Cin));
+    int kh = tap / g.KW, kw = tap % g.KW;
+    size_t npix = (size_t)g.B * g.Ho * g.Wo;
+    size_t p0 = (size_t)blockIdx.y * pix_per_split;
+    size_t p1 = p0 + pix_per_split < npix ? p0 + pix_per_split : npix;
+    float acc = 0.f;
+    for (size_t p = p0; p < p1; ++p) {
+        int ox = (int)(p % g.Wo), oy = (int)((p / g.Wo) % g.Ho), b = (int)(p / ((size_t)g.Wo * g.Ho));
+        int iy, ix;
+        if (!g.transposed) {
+            iy = oy * g.stride - g.pad + kh;
+            ix = ox * g.stride - g.pad + kw;
+        } else {
+            int ty = oy + g.pad - kh, tx = ox + g.pad - kw;
+            if (ty < 0 || tx < 0 || (ty % g.stride) != 0 || (tx % g.stride) != 0) continue;
+            iy = ty / g.stride;
+            ix = tx / g.stride;
+        }
+        if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) continue;
+        acc = fmaf(x[(((size_t)b * g.H + iy) * g.W + ix) * g.Cin + ci], dconv[p * g.Cout + co], acc);
+    }
+    atomicAdd(&dw[e], acc);
+}
+
+// dbias[co] = sum over rows of dconv [npix][Cout]; 4 row lanes x 64 channel lanes per block
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ m, float* __restrict__ out, size_t rows,
+                                                int C, size_t rows_per_split) {
+    __shared__ float red[256];
+    int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    int rl = threadIdx.x >> 6;
+    size_t r0 = (size_t)blockIdx.y * rows_per_split;
+    size_t r1 = r0 + rows_per_split < rows ? r0 + rows_per_split : rows;
+    float acc = 0.f;
+    if (c < C)
+        for (size_t r = r0 + rl; r < r1; r += 4) acc += m[r * C + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(&out[c], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] +
+                                                 red[threadIdx.x + 192]);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+int conv_direct_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
+                    float* y, int act, int ps_r, void* stream) {
+    size_t n = (size_t)g.B * g.Ho * g.Wo * g.Cout;
+    DASR_LAUNCH(k_conv_direct_fwd, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, g, x, w, bias, residual, y, act, ps_r);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+int conv_epilogue_bwd(const ConvGeom& g, const float* dy, const float* y, float* dconv, int act, int ps_r,
+                      void* stream) {
+    size_t n = (size_t)g.B * g.Ho * g.Wo * g.Cout;
+    DASR_LAUNCH(k_conv_epilogue_bwd, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, g, dy, y, dconv, act, ps_r);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+int conv_direct_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream) {
+    size_t n = (size_t)g.B * g.H * g.W * g.Cin;
+    DASR_LAUNCH(k_conv_direct_dgrad, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, g, dconv, w, dx, accumulate);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+int conv_colsum(const float* m, float* out, size_t rows, int C, void* stream) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    unsigned nsplit = (unsigned)((rows + 1023) / 1024);
+    if (nsplit > 1024) nsplit = 1024;
+    if (nsplit < 1) nsplit = 1;
+    size_t rps = (rows + nsplit - 1) / nsplit;
+    DASR_LAUNCH(k_colsum, dim3(dasr_cdiv(C, 64), nsplit), dim3(256), 0, stream, m, out, rows, C, rps);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+int conv_direct_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* stream) {
+    size_t nW = (size_t)g.KH * g.KW * g.Cin * g.Cout;
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * nW, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    size_t npix = (size_t)g.B * g.Ho * g.Wo;
+    unsigned gx = dasr_cdiv(nW, 256);
+    unsigned nsplit = 4096 / gx;
+    if (nsplit < 1) nsplit = 1;
+    size_t max_split = (npix + 63) / 64;
+    if (nsplit > max_split) nsplit = (unsigned)max_split;
+    if (nsplit > 65535) nsplit = 65535;
+    size_t pps = (npix + nsplit - 1) / nsplit;
+    DASR_LAUNCH(k_conv_direct_wgrad, dim3(gx, nsplit), dim3(256), 0, stream, g, x, dconv, dw, pps);
+    DASR_RETURN_LAUNCH_STATUS();
+}

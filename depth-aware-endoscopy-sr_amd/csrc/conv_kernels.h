@@ -1,0 +1,26 @@
+// conv_kernels.h — geometry struct and internal entry points shared by the convolution sources.
+#pragma once
+#include "dasr_common.h"
+
+struct ConvGeom {
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed;
+};
+
+// Output element index with the fused PixelShuffle(ps_r) store (nn.PixelShuffle index map:
+// out[b, c, oy*r+i, ox*r+j] = in[b, c*r*r + i*r + j, oy, ox], here in NHWC).
+__host__ __device__ __forceinline__ size_t conv_out_index(const ConvGeom& g, int b, int oy, int ox, int co, int ps_r) {
+    if (ps_r <= 1) return (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.Cout + co;
+    int rr = ps_r * ps_r;
+    int c = co / rr, i = (co / ps_r) % ps_r, j = co % ps_r;
+    return (((size_t)b * g.Ho * ps_r + (size_t)oy * ps_r + i) * ((size_t)g.Wo * ps_r) + (size_t)ox * ps_r + j) *
+               (g.Cout / rr) + c;
+}
+
+// conv_direct.hip
+int conv_direct_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
+                    float* y, int act, int ps_r, void* stream);
+int conv_epilogue_bwd(const ConvGeom& g, const float* dy, const float* y, float* dconv, int act, int ps_r,
+                      void* stream);
+int conv_direct_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
+int conv_direct_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* stream);
+int conv_colsum(const float* m, float* out, size_t rows, int C, void* stream);

@@ -1,0 +1,72 @@
+// dasr_common.h — shared helpers of the HIP kernel sources (gfx950 only).
+//
+// Every .hip file in this directory is compiled by hipcc --offload-arch=gfx950 into
+// libdasr_hip.so.  The same sources are compiled a second time as host C++ against
+// tests/hipemu/hipemu.h (-DDASR_HIPEMU) so that unit tests can execute the kernels on the
+// CPU of the GPU-less build container; that build is test infrastructure, never shipped.
+#pragma once
+
+#ifdef DASR_HIPEMU
+#include "hipemu.h"
+#define DASR_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
+#define DASR_DYN_SMEM(name) char* name = hipemu::dyn_smem
+#define DASR_DEVICE_BUILD 0
+#else
+#include <hip/hip_runtime.h>
+#define DASR_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (hipStream_t)(stream), __VA_ARGS__)
+#define DASR_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define DASR_DEVICE_BUILD 1
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#endif
+
+#include "../../include/dasr.h"
+
+#define DASR_CHECK_PTR(p) \
+    do {                  \
+        if (!(p)) return DASR_E_NULL; \
+    } while (0)
+#define DASR_CHECK_SHAPE(cond) \
+    do {                       \
+        if (!(cond)) return DASR_E_SHAPE; \
+    } while (0)
+#define DASR_RETURN_LAUNCH_STATUS() return (int)hipGetLastError()
+
+static inline unsigned dasr_cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+// grid size for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, no more
+static inline unsigned dasr_ew_grid(size_t n, unsigned block = 256) {
+    size_t g = (n + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+__device__ __forceinline__ float dasr_act(float v, int act) {
+    if (act == DASR_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DASR_ACT_LRELU02) return v > 0.f ? v : 0.2f * v;
+    return v;
+}
+// derivative wrt the pre-activation, evaluated from the saved OUTPUT (sign-preserving activations)
+__device__ __forceinline__ float dasr_act_grad_from_out(float out, int act) {
+    if (act == DASR_ACT_RELU) return out > 0.f ? 1.f : 0.f;
+    if (act == DASR_ACT_LRELU02) return out > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+
+// Closed form of the two back-to-back InstanceNorm2d(affine=False, eps):
+//   xhat = (x - mean) * s(var),  s(v) = (v+eps)^-1/2 * (v/(v+eps) + eps)^-1/2
+__device__ __forceinline__ float dasr_double_in_scale(float var, float eps) {
+    float r1 = 1.0f / sqrtf(var + eps);
+    float v2 = var / (var + eps);
+    return r1 / sqrtf(v2 + eps);
+}
+// ds/dv of the above
+__device__ __forceinline__ float dasr_double_in_dscale(float var, float eps) {
+    float a = var + eps;
+    float v2 = var / a;
+    float b = v2 + eps;
+    float s = (1.0f / sqrtf(a)) / sqrtf(b);
+    return s * (-0.5f / a - 0.5f * (eps / (a * a)) / b);
+}

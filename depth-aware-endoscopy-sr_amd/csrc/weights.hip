@@ -1,0 +1,90 @@
+// weights.hip — weight_norm (dim 0) + packing of PyTorch-layout kernels into HWIO, and its backward.
+// Reference: torch.nn.utils.weight_norm call sites sftmd_arch.py:741,851 (w = g*v/||v||, norm over all
+// dims but 0; for ConvTranspose2d dim 0 is the in-channel axis).  Tiny tensors: one workgroup per norm
+// group, wave shuffles + LDS for the reduction.
+#include "dasr_common.h"
+
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` against the previous use
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// element (n, r) of a norm group: n = dim-0 index, r = remaining flat index in [0, R)
+// conv:        v[o][i][kh][kw]   n=o, r = i*KK + t      -> w[(t*I + i)*O + o]
+// transposed:  v[i][o][kh][kw]   n=i, r = o*KK + t      -> w[(t*I + i)*O + o]
+__device__ __forceinline__ size_t hwio_index(int n, int r, int ldo, int o_off, int I, int KK, int transposed) {
+    int a = r / KK, t = r % KK;
+    int o = transposed ? a : n;
+    int i = transposed ? n : a;
+    return ((size_t)t * I + i) * ldo + o_off + o;
+}
+
+__global__ void __launch_bounds__(256) k_weight_pack_fwd(const float* __restrict__ v, const float* __restrict__ g,
+                                                         float* __restrict__ w, float* __restrict__ inv_norm, int O,
+                                                         int I, int KK, int transposed, int ldo, int o_off) {
+    __shared__ float red[4];
+    int n = blockIdx.x;
+    int R = (transposed ? O : I) * KK;
+    const float* vn = v + (size_t)n * R;
+    float scale = 1.f;
+    if (g) {
+        float ss = 0.f;
+        for (int r = threadIdx.x; r < R; r += 256) ss += vn[r] * vn[r];
+        ss = block_sum_256(ss, red);
+        float inv = 1.0f / sqrtf(ss);
+        if (threadIdx.x == 0 && inv_norm) inv_norm[n] = inv;
+        scale = g[n] * inv;
+    }
+    for (int r = threadIdx.x; r < R; r += 256) w[hwio_index(n, r, ldo, o_off, I, KK, transposed)] = vn[r] * scale;
+}
+
+// dv = (g/||v||) * (dw - v * <dw,v>/||v||^2) ; dg = <dw,v>/||v||
+__global__ void __launch_bounds__(256) k_weight_pack_bwd(const float* __restrict__ dw, const float* __restrict__ v,
+                                                         const float* __restrict__ g,
+                                                         const float* __restrict__ inv_norm, float* __restrict__ dv,
+                                                         float* __restrict__ dg, int O, int I, int KK, int transposed, int ldo,
+                                                         int o_off) {
+    __shared__ float red[4];
+    int n = blockIdx.x;
+    int R = (transposed ? O : I) * KK;
+    const float* vn = v + (size_t)n * R;
+    float* dvn = dv + (size_t)n * R;
+    if (!g) {
+        for (int r = threadIdx.x; r < R; r += 256) dvn[r] = dw[hwio_index(n, r, ldo, o_off, I, KK, transposed)];
+        return;
+    }
+    float dot = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) dot += dw[hwio_index(n, r, ldo, o_off, I, KK, transposed)] * vn[r];
+    dot = block_sum_256(dot, red);
+    float inv = inv_norm[n];
+    float gn = g[n];
+    if (threadIdx.x == 0) dg[n] = dot * inv;
+    float c1 = gn * inv, c2 = gn * dot * inv * inv * inv;
+    for (int r = threadIdx.x; r < R; r += 256) dvn[r] = c1 * dw[hwio_index(n, r, ldo, o_off, I, KK, transposed)] - c2 * vn[r];
+}
+
+extern "C" int dasr_weight_pack_fwd(const float* v, const float* g, float* w, float* inv_norm, int O, int I, int KH,
+                                    int KW, int transposed, int ldo, int o_off, void* stream) {
+    DASR_CHECK_PTR(v); DASR_CHECK_PTR(w);
+    if (g) DASR_CHECK_PTR(inv_norm);
+    DASR_CHECK_SHAPE(O > 0 && I > 0 && KH > 0 && KW > 0 && o_off >= 0 && ldo >= o_off + O);
+    int groups = transposed ? I : O;
+    DASR_LAUNCH(k_weight_pack_fwd, dim3(groups), dim3(256), 0, stream, v, g, w, inv_norm, O, I, KH * KW, transposed, ldo,
+                o_off);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+extern "C" int dasr_weight_pack_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, float* dv,
+                                    float* dg, int O, int I, int KH, int KW, int transposed, int ldo, int o_off,
+                                    void* stream) {
+    DASR_CHECK_PTR(dw); DASR_CHECK_PTR(v); DASR_CHECK_PTR(dv);
+    if (g) { DASR_CHECK_PTR(inv_norm); DASR_CHECK_PTR(dg); }
+    DASR_CHECK_SHAPE(O > 0 && I > 0 && KH > 0 && KW > 0 && o_off >= 0 && ldo >= o_off + O);
+    int groups = transposed ? I : O;
+    DASR_LAUNCH(k_weight_pack_bwd, dim3(groups), dim3(256), 0, stream, dw, v, g, inv_norm, dv, dg, O, I, KH * KW,
+                transposed, ldo, o_off);
+    DASR_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,310 @@
+"""Forward plan of DepthNet as a sequence of HIP kernel calls recorded on a Tape.
+
+Mirrors DepthNet.forward (reference codes/models/modules/sftmd_arch.py:912-950) and the blocks
+it calls: Encoder.forward (:771-783), Depth_Residual_Block_Mask.forward (:826-834),
+Classic_Residual_Block.forward (:147-151), SEAN.forward (normalization.py:52-92).  What differs
+from the reference is HOW, not WHAT: NHWC activations, the 256-channel style map collapsed into
+per-sample dynamic 3x3 kernels over the K-channel mask, the two instance norms collapsed into one
+scale, gamma_o/beta_o run as one 2C->2C convolution, activation / PixelShuffle / residual fused
+into convolution epilogues.
+"""
+import math
+
+from . import ops
+from .tape import Tape, Var, accum
+
+
+# ---------------------------------------------------------------------------------------------
+# recorded primitives
+# ---------------------------------------------------------------------------------------------
+def pack(tape, v, g=None, transposed=False):
+    """weight_norm (if g) + OIHW -> HWIO."""
+    w, inv = ops.weight_pack(v.data, g.data if g is not None else None, transposed)
+    out = Var(w, v.requires_grad or (g is not None and g.requires_grad))
+
+    def bwd():
+        if out.grad is None:
+            return
+        dv, dg = ops.weight_pack_bwd(out.grad, v.data, g.data if g is not None else None, inv, transposed)
+        out.grad = None
+        accum(v, dv)
+        if g is not None:
+            accum(g, dg)
+
+    tape.record(bwd)
+    return out
+
+
+def pack_pair(tape, va, vb):
+    """Two plain OIHW kernels with equal Cin side by side along Cout (mlp_gamma_o | mlp_beta_o)."""
+    Oa, I, KH, KW = va.data.shape
+    Ob = vb.data.shape[0]
+    w = ops.empty((KH, KW, I, Oa + Ob), va.data)
+    ops.weight_pack(va.data, None, False, out=w, o_off=0)
+    ops.weight_pack(vb.data, None, False, out=w, o_off=Oa)
+    out = Var(w, va.requires_grad or vb.requires_grad)
+
+    def bwd():
+        if out.grad is None:
+            return
+        da, _ = ops.weight_pack_bwd(out.grad, va.data, None, None, False, o_off=0)
+        db, _ = ops.weight_pack_bwd(out.grad, vb.data, None, None, False, o_off=Oa)
+        out.grad = None
+        accum(va, da)
+        accum(vb, db)
+
+    tape.record(bwd)
+    return out
+
+
+def bias_pair(tape, ba, bb):
+    na, nb = ba.data.numel(), bb.data.numel()
+    buf = ops.empty((na + nb,), ba.data)
+    ops.copy_(buf[:na], ba.data)
+    ops.copy_(buf[na:], bb.data)
+    out = Var(buf, ba.requires_grad or bb.requires_grad)
+
+    def bwd():
+        if out.grad is None:
+            return
+        g = out.grad
+        out.grad = None
+        accum(ba, g[:na])
+        accum(bb, g[na:])
+
+    tape.record(bwd)
+    return out
+
+
+def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.ACT_NONE, ps_r=1, residual=None):
+    y = ops.conv2d_fwd(x.data, w.data, bias.data if bias is not None else None,
+                       residual.data if residual is not None else None, stride, pad, transposed, act, ps_r)
+    needs = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad) or \
+        (residual is not None and residual.requires_grad)
+    out = Var(y, needs)
+    KH, KW, Cin, Cout = w.data.shape
+    B, H, W_, _ = x.data.shape
+    Ho, Wo = ops.conv_out_hw(H, W_, KH, KW, stride, pad, transposed)
+
+    def bwd():
+        if out.grad is None:
+            return
+        dy = out.grad
+        out.grad = None
+        if act != ops.ACT_NONE or ps_r > 1:
+            dconv = ops.conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r)
+        else:
+            dconv = dy
+        if w.requires_grad or (bias is not None and bias.requires_grad):
+            dw, db = ops.conv2d_wgrad(x.data, dconv, w.data.shape, stride, pad, transposed,
+                                      want_bias=bias is not None)
+            accum(w, dw)
+            if bias is not None:
+                accum(bias, db)
+        if x.requires_grad:
+            if x.grad is None:
+                x.grad = ops.conv2d_dgrad(dconv, w.data, x.data.shape, stride, pad, transposed)
+            else:
+                ops.conv2d_dgrad(dconv, w.data, x.data.shape, stride, pad, transposed, out=x.grad)
+        if residual is not None:
+            accum(residual, dconv)
+
+    tape.record(bwd)
+    return out
+
+
+def add(tape, a, b):
+    out = Var(ops.add(a.data, b.data), a.requires_grad or b.requires_grad)
+
+    def bwd():
+        if out.grad is None:
+            return
+        g = out.grad
+        out.grad = None
+        accum(a, g)
+        accum(b, g, owned=False)
+
+    tape.record(bwd)
+    return out
+
+
+def region_pool(tape, feat, mask):
+    st, maskr, area = ops.region_pool_fwd(feat.data, mask)
+    out = Var(st, feat.requires_grad)
+
+    def bwd():
+        if out.grad is None:
+            return
+        accum(feat, ops.region_pool_bwd(out.grad, maskr, area, feat.data.shape))
+        out.grad = None
+
+    tape.record(bwd)
+    return out
+
+
+def dynk(tape, st, A_w, A_b, Wg, Wb):
+    stp, D = ops.dynk_fwd(st.data, A_w.data, A_b.data, Wg.data, Wb.data)
+    out = Var(D, True)
+
+    def bwd():
+        if out.grad is None:
+            return
+        if st.grad is None:
+            st.grad = ops.zeros(st.data.shape, st.data)
+        dWg, dWb, dAw, dAb = ops.dynk_bwd(out.grad, st.data, stp, A_w.data, Wg.data, Wb.data, st.grad)
+        out.grad = None
+        accum(Wg, dWg)
+        accum(Wb, dWb)
+        accum(A_w, dAw)
+        accum(A_b, dAb)
+
+    tape.record(bwd)
+    return out
+
+
+def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu):
+    mean, var = ops.instnorm_stats(t.data)
+    y = ops.sean_fwd(t.data, mean, var, gb2.data, mask, D.data, bias_g.data, bias_b.data, alpha_g.data, alpha_b.data,
+                     residual.data if residual is not None else None, relu)
+    out = Var(y, True)
+
+    def bwd():
+        if out.grad is None:
+            return
+        want_dres = residual is not None and residual.requires_grad
+        dt, dgb2, dD, dbg, dbb, dag, dab, dres = ops.sean_bwd(
+            out.grad, y, t.data, mean, var, gb2.data, mask, D.data, bias_g.data, bias_b.data, alpha_g.data,
+            alpha_b.data, relu, want_dres)
+        out.grad = None
+        accum(t, dt)
+        accum(gb2, dgb2)
+        accum(D, dD)
+        accum(bias_g, dbg)
+        accum(bias_b, dbb)
+        accum(alpha_g, dag)
+        accum(alpha_b, dab)
+        if want_dres:
+            accum(residual, dres)
+
+    tape.record(bwd)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# blocks
+# ---------------------------------------------------------------------------------------------
+def _wn(tape, P, prefix, transposed=False):
+    return pack(tape, P[prefix + ".weight_v"], P[prefix + ".weight_g"], transposed)
+
+
+def block_plan(cfg):
+    """Channel plan of DepthNet.__init__ (sftmd_arch.py:879-889): [(module_name, kind, channels)]."""
+    nb, scale = cfg["nb"], cfg["scale"]
+    num_last_block = 1 if scale == 3 else int(math.log(scale, 2))
+    plan = []
+    for i in range(nb):
+        ch = 32 if i > nb - num_last_block else cfg["nf"]
+        kind = "depth" if i in cfg["which_ResBlk_depth"] else "classic"
+        plan.append((("depth-residual%d" if kind == "depth" else "classic-residual%d") % (i + 1), kind, ch))
+    return plan
+
+
+def sean(tape, P, pre, t, depth_map, mask, st, residual, relu, consts):
+    """SEAN.forward (normalization.py:52-92) + the caller's ReLU / residual."""
+    B, H, W, C = t.data.shape
+    assert st.data.shape[1] == mask.shape[1], "depth matrix regions != mask channels"   # normalization.py:54
+    assert st.data.shape[2] == P[pre + ".mlp_gamma_s.weight"].data.shape[1], "len_latent != depth matrix width"
+    # gamma2 / beta2: a function of the depth map only
+    w_m = pack(tape, P[pre + ".mlp_mask.0.weight"])
+    actv = conv(tape, depth_map, w_m, P[pre + ".mlp_mask.0.bias"], act=ops.ACT_RELU)
+    w_gb = pack_pair(tape, P[pre + ".mlp_gamma_o.weight"], P[pre + ".mlp_beta_o.weight"])
+    b_gb = bias_pair(tape, P[pre + ".mlp_gamma_o.bias"], P[pre + ".mlp_beta_o.bias"])
+    gb2 = conv(tape, actv, w_gb, b_gb)
+    # gamma1 / beta1: per-sample dynamic kernels over the K-channel mask
+    D = dynk(tape, st, P[pre + ".A_i_j.weight"], P[pre + ".A_i_j.bias"], P[pre + ".mlp_gamma_s.weight"],
+             P[pre + ".mlp_beta_s.weight"])
+    a_g = P[pre + ".alpha_gamma"] if (pre + ".alpha_gamma") in P else consts["alpha_gamma"]
+    a_b = P[pre + ".alpha_beta"] if (pre + ".alpha_beta") in P else consts["alpha_beta"]
+    return sean_mod(tape, t, gb2, mask, D, P[pre + ".mlp_gamma_s.bias"], P[pre + ".mlp_beta_s.bias"], a_g, a_b,
+                    residual, relu)
+
+
+def depth_block(tape, P, name, x, depth_map, mask, st, consts):
+    """Depth_Residual_Block_Mask.forward (sftmd_arch.py:826-834)."""
+    B, H, W, C = x.data.shape
+    if depth_map.data.shape[1:3] != (H, W):      # F.interpolate(..., mode='nearest'), normalization.py:58-59
+        d = ops.resize_nearest_nchw(depth_map.data.view(B, 1, *depth_map.data.shape[1:3]), H, W)
+        depth_map = Var(d.view(B, H, W, 1))
+        mask = ops.resize_nearest_nchw(mask, H, W)
+    t1 = conv(tape, x, pack(tape, P[name + ".conv1.0.weight"]), P[name + ".conv1.0.bias"])
+    a = sean(tape, P, name + ".norm1", t1, depth_map, mask, st, None, True, consts)
+    t2 = conv(tape, a, pack(tape, P[name + ".conv2.0.weight"]), P[name + ".conv2.0.bias"])
+    return sean(tape, P, name + ".norm2", t2, depth_map, mask, st, x, True, consts)
+
+
+def classic_block(tape, P, name, x):
+    """Classic_Residual_Block.forward (sftmd_arch.py:147-151)."""
+    h = conv(tape, x, _wn(tape, P, name + ".block.0"), P[name + ".block.0.bias"], act=ops.ACT_RELU)
+    return conv(tape, h, _wn(tape, P, name + ".block.2"), P[name + ".block.2.bias"], act=ops.ACT_RELU, residual=x)
+
+
+def upscale(tape, P, name, x, r, second):
+    """upscale1/2/3 (sftmd_arch.py:891-908): conv -> PixelShuffle(r) -> LeakyReLU [-> conv -> LeakyReLU]."""
+    x = conv(tape, x, _wn(tape, P, name + ".0"), P[name + ".0.bias"], act=ops.ACT_LRELU, ps_r=r)
+    if second:
+        x = conv(tape, x, _wn(tape, P, name + ".3"), P[name + ".3.bias"], act=ops.ACT_LRELU)
+    return x
+
+
+def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask):
+    """DepthNet.forward (sftmd_arch.py:912-950). ``inp`` [B,3,H,W], ``depth_map`` [B,1,h,w],
+    ``depth_mask`` [B,K,h,w] are the caller's NCHW tensors; returns (out NCHW tensor, out Var)."""
+    plan = block_plan(cfg)
+    nb, scale = cfg["nb"], cfg["scale"]
+    B = inp.shape[0]
+    x0 = Var(ops.nchw_to_nhwc(inp))
+    dm = Var(depth_map.reshape(B, depth_map.shape[2], depth_map.shape[3], 1))   # [B,1,h,w] == [B,h,w,1]
+    L = ops.ACT_LRELU
+    # Encoder.forward (sftmd_arch.py:771-783)
+    e1 = conv(tape, x0, _wn(tape, P, "encoder.layer1"), P["encoder.layer1.bias"], act=L)
+    st = None
+    if len(cfg["which_ResBlk_depth"]) > 0:
+        e2 = conv(tape, e1, _wn(tape, P, "encoder.layer2"), P["encoder.layer2.bias"], stride=2, act=L)
+        e3 = conv(tape, e2, _wn(tape, P, "encoder.layer3"), P["encoder.layer3.bias"], stride=2, act=L)
+        e4 = conv(tape, e3, _wn(tape, P, "encoder.layer4", True), P["encoder.layer4.bias"], stride=2,
+                  transposed=True, act=L)
+        e5 = conv(tape, e4, _wn(tape, P, "encoder.layer5"), P["encoder.layer5.bias"], stride=2)
+        st = region_pool(tape, e5, depth_mask)
+    # head (:920)
+    h1 = conv(tape, e1, _wn(tape, P, "head.0"), P["head.0.bias"], act=L)
+    fea_bef = conv(tape, h1, _wn(tape, P, "head.2"), P["head.2.bias"], act=L)
+
+    def run_block(i, x):
+        name, kind, _ = plan[i]
+        if kind == "depth":
+            return depth_block(tape, P, name, x, dm, depth_mask, st, consts)
+        return classic_block(tape, P, name, x)
+
+    fea = fea_bef
+    for i in range(nb - 3):                       # :923 — block index nb-3 is constructed but never called
+        fea = run_block(i, fea)
+    fea = add(tape, fea, fea_bef)                 # :931
+    if scale == 8:
+        fea = upscale(tape, P, "upscale1", fea, 2, True)
+    fea = run_block(nb - 2, fea)
+    if scale >= 4:
+        fea = upscale(tape, P, "upscale2", fea, 2, True)
+    fea = run_block(nb - 1, fea)
+    fea = upscale(tape, P, "upscale3", fea, 3 if scale == 3 else 2, False)
+    y = conv(tape, fea, pack(tape, P["conv_output.weight"]), P["conv_output.bias"], pad=4)     # :948
+    lo, hi = cfg["out_min"], cfg["out_max"]
+    out = Var(ops.clamp_to_nchw(y.data, lo, hi), True)                                          # :950
+
+    def bwd():
+        if out.grad is None:
+            return
+        accum(y, ops.clamp_to_nchw_bwd(out.grad, y.data, lo, hi))
+        out.grad = None
+
+    tape.record(bwd)
+    return out

@@ -1,0 +1,245 @@
+"""Tensor-level wrappers of the C ABI (include/dasr.h).
+
+PyTorch is used here for device memory (``torch.empty``) and the current stream only; every
+computation is a call into libdasr_hip.so.  Activations are NHWC ``[B,H,W,C]`` fp32, kernels
+are HWIO ``[KH,KW,Cin,Cout]``.
+"""
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+IN_EPS = 1e-5  # nn.InstanceNorm2d default eps (sftmd_arch.py:813, normalization.py:17)
+
+
+def _p(t, allow_none=False):
+    return _lib.ptr(t, allow_none)
+
+
+def _call(name, *args):
+    fn = getattr(_lib.get(), name)
+    _lib.check(fn(*args, _lib.stream()), name)
+
+
+def empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# ---- edge ----------------------------------------------------------------------------------
+def nchw_to_nhwc(x):
+    B, C, H, W = x.shape
+    out = empty((B, H, W, C), x)
+    _call("dasr_nchw_to_nhwc", _p(x), _p(out), B, C, H, W)
+    return out
+
+
+def nhwc_to_nchw(x):
+    B, H, W, C = x.shape
+    out = empty((B, C, H, W), x)
+    _call("dasr_nhwc_to_nchw", _p(x), _p(out), B, C, H, W)
+    return out
+
+
+def clamp_to_nchw(y, lo, hi):
+    B, H, W, C = y.shape
+    out = empty((B, C, H, W), y)
+    _call("dasr_clamp_to_nchw", _p(y), _p(out), B, C, H, W, float(lo), float(hi))
+    return out
+
+
+def clamp_to_nchw_bwd(dout, y, lo, hi):
+    B, H, W, C = y.shape
+    dy = empty(y.shape, y)
+    _call("dasr_clamp_to_nchw_bwd", _p(dout), _p(y), _p(dy), B, C, H, W, float(lo), float(hi))
+    return dy
+
+
+def resize_nearest_nchw(x, H, W):
+    B, C, h, w = x.shape
+    if (h, w) == (H, W):
+        return x
+    out = empty((B, C, H, W), x)
+    _call("dasr_resize_nearest_nchw", _p(x), _p(out), B * C, h, w, H, W)
+    return out
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    _call("dasr_add", _p(a), _p(b), _p(out), a.numel())
+    return out
+
+
+def accumulate_(dst, src):
+    assert dst.shape == src.shape
+    _call("dasr_accumulate", _p(dst), _p(src), dst.numel())
+    return dst
+
+
+def copy_(dst, src):
+    assert dst.numel() == src.numel()
+    _call("dasr_copy", _p(dst), _p(src), dst.numel())
+    return dst
+
+
+def zeros(shape, like):
+    return torch.zeros(shape, dtype=torch.float32, device=like.device)
+
+
+# ---- weights ------------------------------------------------------------------------------
+def weight_pack(v, g, transposed=False, out=None, o_off=0):
+    """Pack a PyTorch-layout kernel (optionally weight-normed) into HWIO. Returns (w_hwio, inv_norm)."""
+    if transposed:
+        I, O, KH, KW = v.shape
+    else:
+        O, I, KH, KW = v.shape
+    if out is None:
+        out = empty((KH, KW, I, O), v)
+    ldo = out.shape[3]
+    inv = empty((I if transposed else O,), v) if g is not None else None
+    _call("dasr_weight_pack_fwd", _p(v), _p(g, True), _p(out), _p(inv, True), O, I, KH, KW, int(transposed), ldo,
+          int(o_off))
+    return out, inv
+
+
+def weight_pack_bwd(dw, v, g, inv, transposed=False, o_off=0):
+    if transposed:
+        I, O, KH, KW = v.shape
+    else:
+        O, I, KH, KW = v.shape
+    dv = torch.empty_like(v)
+    dg = torch.empty_like(g) if g is not None else None
+    _call("dasr_weight_pack_bwd", _p(dw), _p(v), _p(g, True), _p(inv, True), _p(dv), _p(dg, True), O, I, KH, KW,
+          int(transposed), dw.shape[3], int(o_off))
+    return dv, dg
+
+
+# ---- convolution ----------------------------------------------------------------------------
+def conv_out_hw(H, W, KH, KW, stride, pad, transposed):
+    if transposed:
+        return (H - 1) * stride - 2 * pad + KH, (W - 1) * stride - 2 * pad + KW
+    return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+
+
+def conv2d_fwd(x, w, bias=None, residual=None, stride=1, pad=1, transposed=False, act=ACT_NONE, ps_r=1):
+    B, H, W, Cin = x.shape
+    KH, KW, wi, Cout = w.shape
+    assert wi == Cin, (w.shape, x.shape)
+    Ho, Wo = conv_out_hw(H, W, KH, KW, stride, pad, transposed)
+    if ps_r > 1:
+        y = empty((B, Ho * ps_r, Wo * ps_r, Cout // (ps_r * ps_r)), x)
+    else:
+        y = empty((B, Ho, Wo, Cout), x)
+    _call("dasr_conv2d_fwd", _p(x), _p(w), _p(bias, True), _p(residual, True), _p(y), B, H, W, Cin, Ho, Wo, Cout, KH,
+          KW, stride, pad, int(transposed), act, ps_r)
+    return y
+
+
+def conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r):
+    B = y.shape[0]
+    dconv = empty((B, Ho, Wo, Cout), y)
+    _call("dasr_conv2d_epilogue_bwd", _p(dy), _p(y), _p(dconv), B, Ho, Wo, Cout, act, ps_r)
+    return dconv
+
+
+def conv2d_dgrad(dconv, w, x_shape, stride=1, pad=1, transposed=False, out=None):
+    B, H, W, Cin = x_shape
+    KH, KW, _, Cout = w.shape
+    _, Ho, Wo, _ = dconv.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty(x_shape, dtype=torch.float32, device=dconv.device)
+    _call("dasr_conv2d_dgrad", _p(dconv), _p(w), _p(out), int(acc), B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad,
+          int(transposed))
+    return out
+
+
+def conv2d_wgrad(x, dconv, w_shape, stride=1, pad=1, transposed=False, want_bias=True):
+    B, H, W, Cin = x.shape
+    KH, KW, _, Cout = w_shape
+    _, Ho, Wo, _ = dconv.shape
+    lib = _lib.get()
+    nbytes = lib.dasr_conv2d_wgrad_workspace(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, int(transposed))
+    ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
+    dw = empty(w_shape, x)
+    db = empty((Cout,), x) if want_bias else None
+    _call("dasr_conv2d_wgrad", _p(x), _p(dconv), _p(dw), _p(db, True), _p(ws), nbytes, B, H, W, Cin, Ho, Wo, Cout, KH,
+          KW, stride, pad, int(transposed))
+    return dw, db
+
+
+# ---- instance norm / SEAN -------------------------------------------------------------------
+def instnorm_stats(x):
+    B, H, W, C = x.shape
+    mean = empty((B, C), x)
+    var = empty((B, C), x)
+    _call("dasr_instnorm_stats", _p(x), _p(mean), _p(var), B, H * W, C)
+    return mean, var
+
+
+def dynk_fwd(st, A_w, A_b, Wg, Wb):
+    B, K, L = st.shape
+    C = Wg.shape[0]
+    stp = torch.empty_like(st)
+    D = empty((B, 2, 9, K, C), st)
+    _call("dasr_dynk_fwd", _p(st), _p(A_w), _p(A_b), _p(Wg), _p(Wb), _p(stp), _p(D), B, K, L, C)
+    return stp, D
+
+
+def dynk_bwd(dD, st, stp, A_w, Wg, Wb, dst_accum):
+    """Returns (dWg, dWb, dA_w, dA_b); adds the depth-matrix gradient into ``dst_accum`` in place."""
+    B, K, L = st.shape
+    C = Wg.shape[0]
+    dWg, dWb = torch.empty_like(Wg), torch.empty_like(Wb)
+    dA_w = torch.empty_like(A_w)
+    dA_b = empty((K,), st)
+    scratch = torch.empty_like(st)
+    _call("dasr_dynk_bwd", _p(dD), _p(st), _p(stp), _p(A_w), _p(Wg), _p(Wb), _p(dWg), _p(dWb), _p(dA_w), _p(dA_b),
+          _p(dst_accum), _p(scratch), B, K, L, C)
+    return dWg, dWb, dA_w, dA_b
+
+
+def sean_fwd(t, mean, var, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu):
+    B, H, W, C = t.shape
+    K = mask.shape[1]
+    assert mask.shape == (B, K, H, W) and gb2.shape == (B, H, W, 2 * C) and D.shape == (B, 2, 9, K, C)
+    out = torch.empty_like(t)
+    _call("dasr_sean_fwd", _p(t), _p(mean), _p(var), _p(gb2), _p(mask), _p(D), _p(bias_g), _p(bias_b), _p(alpha_g),
+          _p(alpha_b), _p(residual, True), _p(out), int(relu), B, H, W, C, K, IN_EPS)
+    return out
+
+
+def sean_bwd(dout, out, t, mean, var, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, relu, want_dres):
+    B, H, W, C = t.shape
+    K = mask.shape[1]
+    lib = _lib.get()
+    nbytes = lib.dasr_sean_bwd_workspace(B, H, W, C, K)
+    ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=t.device)
+    dt = torch.empty_like(t)
+    dgb2 = torch.empty_like(gb2)
+    dD = torch.empty_like(D)
+    dbg, dbb = empty((C,), t), empty((C,), t)
+    dag, dab = empty((1,), t), empty((1,), t)
+    dres = torch.empty_like(t) if want_dres else None
+    _call("dasr_sean_bwd", _p(dout), _p(out), _p(t), _p(mean), _p(var), _p(gb2), _p(mask), _p(D), _p(bias_g),
+          _p(bias_b), _p(alpha_g), _p(alpha_b), _p(dt), _p(dgb2), _p(dD), _p(dbg), _p(dbb), _p(dag), _p(dab),
+          _p(dres, True), _p(ws), nbytes, int(relu), B, H, W, C, K, IN_EPS)
+    return dt, dgb2, dD, dbg, dbb, dag, dab, dres
+
+
+# ---- region pooling -------------------------------------------------------------------------
+def region_pool_fwd(feat, mask):
+    B, h, w, L = feat.shape
+    _, K, H, W = mask.shape
+    maskr = empty((B, K, h, w), feat)
+    area = empty((B, K), feat)
+    out = empty((B, K, L), feat)
+    _call("dasr_region_pool_fwd", _p(feat), _p(mask), _p(maskr), _p(area), _p(out), B, K, L, h, w, H, W)
+    return out, maskr, area
+
+
+def region_pool_bwd(dout, maskr, area, feat_shape):
+    B, h, w, L = feat_shape
+    K = maskr.shape[1]
+    dfeat = torch.empty(feat_shape, dtype=torch.float32, device=dout.device)
+    _call("dasr_region_pool_bwd", _p(dout), _p(maskr), _p(area), _p(dfeat), B, K, L, h, w)
+    return dfeat

@@ -26,6 +26,22 @@ __all__ = [
 ]
 
 
+_MASK64 = (1 << 64) - 1
+
+
+def hash_uniform(n: int, key: str) -> torch.Tensor:
+    """``n`` reproducible pseudo-random float64 values in [0,1): splitmix64 of ``(crc32(key) << 32) + i``.
+    Pure integer arithmetic, so every machine regenerates identical values (no RNG state involved)."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = (np.arange(n, dtype=np.uint64) + np.uint64((zlib.crc32(key.encode()) << 32) & _MASK64))
+        z = (z + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return torch.from_numpy((z >> np.uint64(11)).astype(np.float64) / float(1 << 53))
+
+
 def depth_to_masks(depth: torch.Tensor, num_masks: int = 10, fixed_range: bool = False) -> torch.Tensor:
     """Binary depth-range masks ``[K,h,w]`` from one depth map ``[1,h,w]`` (or ``[h,w]``).
 
@@ -83,20 +99,23 @@ def seeded_batch(first_idx: int, batch: int, H: int, W: int, scale: int, num_mas
 
 
 def closed_form_frame(frame_idx: int, H: int, W: int, scale: int, num_masks: int = 10):
-    """RNG-free frame (sines of the pixel coordinates) used by the golden fixtures,
-    so that the fixture files only have to store expected outputs."""
+    """RNG-free frame used by the golden fixtures (integer-hash noise for LQ/GT, a smooth sine field for
+    the depth map so that the depth regions are contiguous), so that the fixture files only have to
+    store expected outputs."""
     y = torch.arange(H, dtype=torch.float32).view(1, H, 1)
     x = torch.arange(W, dtype=torch.float32).view(1, 1, W)
     c = torch.arange(3, dtype=torch.float32).view(3, 1, 1)
     f = float(frame_idx)
-    lq = 0.5 + 0.5 * torch.sin(0.71 * x + 0.53 * y + 1.3 * c + 0.9 * f) * torch.cos(0.37 * x - 0.29 * y + 0.4 * c)
+    lq = hash_uniform(3 * H * W, "lq%d" % frame_idx).reshape(3, H, W).to(torch.float32)
     depth = 0.01 + 9.99 * (0.5 + 0.5 * torch.sin(0.23 * x + 0.31 + 0.2 * f) * torch.cos(0.19 * y + 0.1 * f)
                            * torch.cos(0.05 * x * y / max(H, W) + 0.3))
     depth = depth.reshape(1, H, W)
     masks = depth_to_masks(depth, num_masks)
     ys = torch.arange(H * scale, dtype=torch.float32).view(1, -1, 1)
     xs = torch.arange(W * scale, dtype=torch.float32).view(1, 1, -1)
-    gt = 0.5 + 0.5 * torch.sin(0.11 * xs + 0.07 * ys + 1.1 * c + 0.9 * f) * torch.cos(0.05 * xs - 0.03 * ys)
+    gt = (0.25 * (1.0 + torch.sin(0.11 * xs + 0.07 * ys + 1.1 * c + 0.9 * f) * torch.cos(0.05 * xs - 0.03 * ys))
+          + 0.5 * hash_uniform(3 * H * W * scale * scale, "gt%d" % frame_idx).reshape(3, H * scale, W * scale)
+          ).to(torch.float32)
     return lq, gt, depth, masks
 
 
@@ -111,7 +130,9 @@ def _phase(name: str) -> float:
 
 @torch.no_grad()
 def closed_form_fill_(named_tensors, gain: float = 1.0):
-    """Fill parameters in place with ``a_name * sin(0.37*i + phi_name)``.
+    """Fill parameters in place with RNG-free integer-hash noise of role-dependent amplitude (SURVEY.md §8d
+    asks for a closed-form fill both sides can regenerate; a pure sine fill makes some instance-norm
+    channels nearly constant, which turns the parity check into a test of rounding noise).
 
     ``named_tensors`` is an iterable of ``(name, tensor)`` (``state_dict().items()`` or
     ``named_parameters()``).  Amplitudes follow the tensor's role so that a randomly
@@ -121,8 +142,7 @@ def closed_form_fill_(named_tensors, gain: float = 1.0):
     """
     for name, t in named_tensors:
         n = t.numel()
-        i = torch.arange(n, dtype=torch.float64)
-        wave = torch.sin(0.37 * i + _phase(name))
+        wave = (2.0 * hash_uniform(n, name) - 1.0)        # uniform in [-1, 1)
         leaf = name.rsplit(".", 1)[-1]
         if leaf == "alpha_gamma":
             vals = torch.full((n,), 0.7, dtype=torch.float64)
@@ -138,7 +158,7 @@ def closed_form_fill_(named_tensors, gain: float = 1.0):
             vals = 1.0 + 0.1 * wave
         else:  # convolution kernels (weight / weight_v)
             fan_in = max(1, n // t.shape[0])
-            amp = gain * math.sqrt(2.0) / math.sqrt(fan_in)
+            amp = gain * math.sqrt(6.0) / math.sqrt(fan_in)   # uniform(-a,a) with variance 2/fan_in
             if name.startswith("conv_output"):
                 amp *= 0.75
             vals = amp * wave

@@ -1,0 +1,175 @@
+/*
+ * dasr.h — C ABI of the MI355X-native DepthNet hot path (libdasr_hip.so).
+ *
+ * The reference (CUHK-AIM-Group/Depth-Aware-Endoscopy-SR) is pure Python: the generator
+ * DepthNet (codes/models/modules/sftmd_arch.py:837-950) and its SEAN/DFN normalisation
+ * (codes/models/modules/normalization.py:7-92) dispatch every device op through torch.nn
+ * (cuDNN/cuBLAS/ATen). It has no FFI of its own; these entry points are what a binding
+ * for this path replaces, one per group of torch ops, each citing the reference lines.
+ * INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no torch types; every pointer is DEVICE memory (HBM),
+ *     fp32 unless stated; the caller owns all buffers (outputs and workspaces included).
+ *   - activations are NHWC  [B][H][W][C]  (C fastest); the NCHW tensors of the reference
+ *     API (input image, depth masks, output image) are converted at the edge by
+ *     dasr_nchw_to_nhwc / dasr_clamp_to_nchw or read in place (masks).
+ *   - convolution kernels are packed "HWIO"  [KH][KW][Cin][Cout]  by dasr_weight_pack_fwd.
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, never
+ *     synchronise, never allocate, never throw.  Re-entrant: no global mutable state.
+ *   - return value: 0 on success, a DASR_E_* code (<0) for bad arguments, or a positive
+ *     hipError_t from the launch.  dasr_error_string() names the DASR_E_* codes.
+ */
+#ifndef DASR_H
+#define DASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DASR_OK 0
+#define DASR_E_NULL (-1)        /* a required pointer is NULL                         */
+#define DASR_E_SHAPE (-2)       /* sizes inconsistent with each other or non-positive  */
+#define DASR_E_UNSUPPORTED (-3) /* valid request this build has no kernel for          */
+#define DASR_E_WORKSPACE (-4)   /* workspace too small                                 */
+
+/* activation / epilogue selectors for the convolution entry points */
+#define DASR_ACT_NONE 0
+#define DASR_ACT_RELU 1
+#define DASR_ACT_LRELU02 2 /* LeakyReLU(0.2): sftmd_arch.py:741,861-866,891-908 */
+
+int dasr_version(void);
+const char* dasr_error_string(int code);
+/* 1 when the library was built for the GPU (gfx950), 0 for the CPU kernel emulator used by unit tests */
+int dasr_is_device_build(void);
+
+/* ---- layout at the API edge ------------------------------------------------------------ */
+/* [B,C,H,W] -> [B,H,W,C]; replaces nothing in the reference (it is NCHW throughout). */
+int dasr_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+int dasr_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+/* torch.clamp(out, min, max) (sftmd_arch.py:950) fused with the NHWC->NCHW edge conversion. */
+int dasr_clamp_to_nchw(const float* y_nhwc, float* out_nchw, int B, int C, int H, int W, float lo, float hi,
+                       void* stream);
+/* backward of the above: dy = dout where lo <= y <= hi, else 0. */
+int dasr_clamp_to_nchw_bwd(const float* dout_nchw, const float* y_nhwc, float* dy_nhwc, int B, int C, int H, int W,
+                           float lo, float hi, void* stream);
+/* F.interpolate(mode='nearest') of an NCHW tensor (normalization.py:58-59). */
+int dasr_resize_nearest_nchw(const float* src, float* dst, int BC, int h, int w, int H, int W, void* stream);
+
+/* ---- weights -------------------------------------------------------------------------------
+ * torch.nn.utils.weight_norm, dim 0 (sftmd_arch.py:741,851 and every wn(...) site):
+ *   w = g * v / ||v||  with the norm over all dims but 0.
+ * v is [O][I][KH][KW] for Conv2d, [I][O][KH][KW] for ConvTranspose2d (transposed=1: dim 0 is the
+ * IN-channel axis, encoder.layer4).  g == NULL packs a plain weight (no normalisation).
+ * Output: w_hwio [KH][KW][I][ldo], written at output-channel offset o_off (ldo >= o_off + O lets several
+ * modules share one packed kernel: mlp_gamma_o | mlp_beta_o, normalization.py:41-42, run as one 2C->2C conv);
+ * inv_norm [O or I] (1/||v||, kept for the backward; may be NULL when g is).
+ */
+int dasr_weight_pack_fwd(const float* v, const float* g, float* w_hwio, float* inv_norm, int O, int I, int KH, int KW,
+                         int transposed, int ldo, int o_off, void* stream);
+/* given dW (HWIO): dv (layout of v) and dg ([O or I]); g == NULL: dv = unpacked dW, dg untouched. */
+int dasr_weight_pack_bwd(const float* dw_hwio, const float* v, const float* g, const float* inv_norm, float* dv,
+                         float* dg, int O, int I, int KH, int KW, int transposed, int ldo, int o_off, void* stream);
+
+/* ---- convolution (NHWC, HWIO) -------------------------------------------------------------
+ * Replaces nn.Conv2d / nn.ConvTranspose2d (+ bias, + LeakyReLU/ReLU, + nn.PixelShuffle, + the
+ * residual add of Classic_Residual_Block) at sftmd_arch.py:743-749,811-820,861-866,133-151,891-910
+ * and normalization.py:37-42.
+ *   transposed = 0:  y[b,oy,ox,co] = bias[co] + sum x[b, oy*stride-pad+kh, ox*stride-pad+kw, ci] * w[kh,kw,ci,co]
+ *   transposed = 1:  ConvTranspose2d geometry, Ho = (H-1)*stride - 2*pad + KH.
+ * Epilogue: (+ residual[b,oy,ox,co]) -> act -> PixelShuffle(ps_r):
+ *   ps_r > 1 writes y as [B][Ho*r][Wo*r][Cout/r^2] with
+ *   y[b, oy*r+i, ox*r+j, c] = act(conv[b,oy,ox, c*r*r + i*r + j])   (bit-exact index map of nn.PixelShuffle).
+ * bias, residual may be NULL.
+ */
+int dasr_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, const float* residual, float* y, int B,
+                    int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                    int transposed, int act, int ps_r, void* stream);
+/* Backward of the epilogue: dconv[b,oy,ox,cc] = dy[...shuffled...] * act'(y[...]) (y = saved forward output). */
+int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, int B, int Ho, int Wo, int Cout, int act,
+                             int ps_r, void* stream);
+/* dx (+)= conv-transpose of dconv with w; accumulate != 0 adds into dx. */
+int dasr_conv2d_dgrad(const float* dconv, const float* w_hwio, float* dx, int accumulate, int B, int H, int W, int Cin,
+                      int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int transposed, void* stream);
+/* dw_hwio = sum_pixels x (x) dconv ; dbias[co] = sum dconv (dbias may be NULL).
+ * workspace: dasr_conv2d_wgrad_workspace() bytes. */
+size_t dasr_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                   int pad, int transposed);
+int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw_hwio, float* dbias, void* workspace,
+                      size_t workspace_bytes, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                      int stride, int pad, int transposed, void* stream);
+
+/* ---- instance-norm statistics ---------------------------------------------------------------
+ * nn.InstanceNorm2d(affine=False) appears twice in a row on every DGB conv output
+ * (sftmd_arch.py:811-820 then normalization.py:16-17,56).  Both collapse to one per-(b,c) scale:
+ *   xhat = (x - mean) * rsqrt(var+eps) * rsqrt(var/(var+eps) + eps)      
+ * This entry point computes mean and biased variance per (b,c) of an NHWC tensor.
+ */
+int dasr_instnorm_stats(const float* x, float* mean, float* var, int B, int HW, int C, void* stream);
+
+/* ---- depth matrix -> per-sample dynamic kernels ------------------------------------------------
+ * SEAN.A_i_j (1x1 conv over the K axis) and the collapse of mlp_gamma_s / mlp_beta_s over the
+ * style map (normalization.py:27-29,80-85):
+ *   stp[b,k,l]       = A_b[k] + sum_j A_w[k,j] * st[b,j,l]
+ *   D[b,s,tap,k,c]   = sum_l W_s[c,l,tap] * stp[b,k,l]          s = 0 (gamma), 1 (beta); tap = kh*3+kw
+ * W_gamma / W_beta are the module's OIHW tensors [C][L][3][3].
+ */
+int dasr_dynk_fwd(const float* st, const float* A_w, const float* A_b, const float* W_gamma, const float* W_beta,
+                  float* stp, float* D, int B, int K, int L, int C, void* stream);
+/* Given dD: dW_gamma, dW_beta (written), dA_w, dA_b (written), dst (ACCUMULATED: the depth matrix feeds every SEAN).
+ * dstp is a [B,K,L] scratch. */
+int dasr_dynk_bwd(const float* dD, const float* st, const float* stp, const float* A_w, const float* W_gamma,
+                  const float* W_beta, float* dW_gamma, float* dW_beta, float* dA_w, float* dA_b, float* dst,
+                  float* dstp, int B, int K, int L, int C, void* stream);
+
+/* ---- the Depth-Guided Block's dynamic convolution + DFN modulation (north-star kernel) ----------
+ * Replaces, per SEAN call (normalization.py:56,59,80-89) and the surrounding ReLU / residual of
+ * Depth_Residual_Block_Mask.forward (sftmd_arch.py:826-834):
+ *   xhat   = double instance norm of t (stats from dasr_instnorm_stats)
+ *   gamma1 = bias_gamma[c] + sum_{tap,k} mask[b,k,p+tap] * D[b,0,tap,k,c]       (zero padding)
+ *   beta1  = bias_beta[c]  + sum_{tap,k} mask[b,k,p+tap] * D[b,1,tap,k,c]
+ *   gamma  = a_g*gamma1 + (1-a_g)*gamma2 ;  beta = a_b*beta1 + (1-a_b)*beta2
+ *   out    = xhat*(1+gamma) + beta  (+ residual)  -> ReLU if relu != 0
+ * t, out, residual: NHWC [B,H,W,C]; gb2: NHWC [B,H,W,2C] (gamma2 | beta2 = mlp_gamma_o | mlp_beta_o outputs);
+ * mask: NCHW [B,K,H,W] as the reference delivers it (any float values); bias_gamma/bias_beta [C] are the
+ * mlp_gamma_s / mlp_beta_s biases; alpha_gamma / alpha_beta are 1-element DEVICE tensors (trainable, normalization.py:30-35).
+ */
+int dasr_sean_fwd(const float* t, const float* mean, const float* var, const float* gb2, const float* mask,
+                  const float* D, const float* bias_gamma, const float* bias_beta, const float* alpha_gamma,
+                  const float* alpha_beta, const float* residual, float* out, int relu, int B, int H, int W, int C,
+                  int K, float eps, void* stream);
+/* Backward. Inputs as forward plus dout and the saved forward output `out` (for the ReLU mask).
+ * Outputs: dt [B,H,W,C]; dgb2 [B,H,W,2C]; dD [B,2,9,K,C]; dbias_gamma, dbias_beta [C]; dalpha_gamma, dalpha_beta [1];
+ * dres (may be NULL; written = dout*relu') ; workspace: dasr_sean_bwd_workspace() bytes. */
+size_t dasr_sean_bwd_workspace(int B, int H, int W, int C, int K);
+int dasr_sean_bwd(const float* dout, const float* out, const float* t, const float* mean, const float* var,
+                  const float* gb2, const float* mask, const float* D, const float* bias_gamma, const float* bias_beta,
+                  const float* alpha_gamma, const float* alpha_beta, float* dt, float* dgb2, float* dD,
+                  float* dbias_gamma, float* dbias_beta, float* dalpha_gamma, float* dalpha_beta, float* dres,
+                  void* workspace, size_t workspace_bytes, int relu, int B, int H, int W, int C, int K, float eps,
+                  void* stream);
+
+/* ---- region-wise average pooling (depth matrix) ---------------------------------------------------
+ * RegionWiseAvgPooling.forward (sftmd_arch.py:714-733): masks are resized to the feature size with
+ * bilinear(align_corners=True) and re-binarised (>= 0.5) when sizes differ; per region
+ *   out[b,k,l] = sum_p m[b,k,p]*feat[b,p,l] / (sum_p m[b,k,p] + 1e-10).
+ * feat NHWC [B,h,w,L]; mask NCHW [B,K,H,W]; maskr NCHW [B,K,h,w] and area [B,K] are written and
+ * kept for the backward.
+ */
+int dasr_region_pool_fwd(const float* feat, const float* mask, float* maskr, float* area, float* out, int B, int K,
+                         int L, int h, int w, int H, int W, void* stream);
+int dasr_region_pool_bwd(const float* dout, const float* maskr, const float* area, float* dfeat, int B, int K, int L,
+                         int h, int w, void* stream);
+
+/* ---- small elementwise helpers ---------------------------------------------------------------- */
+int dasr_add(const float* a, const float* b, float* out, size_t n, void* stream);  /* torch.add, sftmd_arch.py:931 */
+int dasr_accumulate(float* dst, const float* src, size_t n, void* stream);         /* dst += src (gradient fan-in) */
+int dasr_copy(float* dst, const float* src, size_t n, void* stream);               /* device-to-device copy */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DASR_H */

@@ -137,6 +137,13 @@ for case in DEPTHNET_CASES:
     cfg = make_case_cfg(case)
     net = ref_net(cfg)
     lq, gt, dmap, dmask = synth.closed_form_batch(0, case["B"], case["H"], case["W"], cfg["scale"])
+    # (a) gradients of a LINEAR functional of the output (smooth: no sign() of the L1 loss in the way)
+    sr = net(lq, dmap, dmask)
+    wgt = torch.cos(torch.arange(sr.numel(), dtype=sr.dtype) * 0.013).reshape(sr.shape)
+    (sr * wgt).sum().backward()
+    lin = {"gl." + k: grad_digest(p.grad) for k, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=True)
+    # (b) the training loss of the reference harness
     sr = net(lq, dmap, dmask)
     dyn = mask_loss.dynamic_weight_mask_loss(opt_dyn, num_trainable_para=cfg["depthRangeNum"])
     per, wl, l_dyn, sm = dyn(sr, gt, dmask)
@@ -152,6 +159,7 @@ for case in DEPTHNET_CASES:
         else:
             arrays["g." + k] = grad_digest(p.grad)
     arrays["nograd"] = np.array(nograd)
+    arrays.update(lin)
     save("depthnet_" + case["name"], **arrays)
 
 # state_dict key/shape list of the full x8 / x4 / x2 nets

@@ -1,0 +1,339 @@
+"""Parity checks of the HIP path (dasr_amd) shared by the CPU-emulator tests (-m "not gpu") and the
+GPU tests (-m gpu).  ``device`` is 'cpu' when the kernels run in tests/hipemu, 'cuda' on the MI355X."""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from dasr_amd import graph, ops, synth
+from dasr_amd.depthnet import DepthNet
+from dasr_amd.tape import Tape, Var
+from oracle import depthnet_oracle as O
+from tests.golden_cases import (DEPTHNET_CASES, SEAN_CASES, block_inputs, grad_digest, make_case_cfg, pool_inputs,
+                                sean_inputs)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def rel_max(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return (a - b).abs().max().item() / max(1e-30, b.abs().max().item())
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def build_net(case, device):
+    cfg = make_case_cfg(case)
+    net = DepthNet(which_ResBlk_depth=cfg["which_ResBlk_depth"], in_nc=3, out_nc=3, nf=64, nb=cfg["nb"],
+                   scale=cfg["scale"], depth_latent_ch=cfg["depth_latent_ch"], depthRangeNum=10)
+    synth.closed_form_fill_(net.state_dict().items())
+    return net.to(device), cfg
+
+
+def digest_global_rel_l2(named_grads, golden, prefix, skip=()):
+    num = den = 0.0
+    worst = (0.0, None)
+    for k, gten in named_grads:
+        if any(s in k for s in skip):
+            continue
+        want = np.asarray(golden[prefix + k], dtype=np.float64)
+        got = grad_digest(gten.cpu())
+        assert got.shape == want.shape, (k, got.shape, want.shape)
+        num += float(((got - want) ** 2).sum())
+        den += float((want ** 2).sum())
+        r = float(np.abs(got - want).max()) / max(1e-30, float(np.abs(want).max()))
+        if r > worst[0]:
+            worst = (r, k)
+    return math.sqrt(num / max(den, 1e-300)), worst
+
+
+# conv biases directly in front of an InstanceNorm have a mathematically zero gradient: pure rounding noise
+ZERO_GRAD_KEYS = (".conv1.0.bias", ".conv2.0.bias")
+
+
+def check_depthnet_case(case, device, lin_tol=2e-3, loss_tol=0.1):
+    g = load("depthnet_" + case["name"])
+    net, cfg = build_net(case, device)
+    lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, case["B"], case["H"], case["W"], cfg["scale"])]
+    # forward (no grad) vs the reference's output
+    with torch.no_grad():
+        sr0 = net(lq, dm, mk)
+    ref = torch.from_numpy(g["sr"])
+    assert tuple(sr0.shape) == tuple(ref.shape)
+    err = (sr0.cpu() - ref).abs().max().item()
+    assert err <= 2e-4, ("forward", case["name"], err)
+    gt_c = gt.cpu()
+    dpsnr = abs(O.psnr_255(sr0.cpu(), gt_c) - O.psnr_255(ref, gt_c))
+    assert dpsnr <= 1e-3, ("psnr", dpsnr)            # north_star: within 1e-3 PSNR (fp32)
+    nograd = set(g["nograd"].tolist())
+    # (a) linear functional of the output
+    sr = net(lq, dm, mk)
+    assert torch.equal(sr.detach(), sr0)             # recorded and unrecorded forwards are the same kernels
+    wgt = torch.cos(torch.arange(sr.numel(), dtype=torch.float32) * 0.013).reshape(sr.shape).to(device)
+    (sr * wgt).sum().backward()
+    named = []
+    for k, p in net.named_parameters():
+        if k in nograd:
+            assert p.grad is None, k
+        else:
+            assert p.grad is not None, k
+            named.append((k, p.grad.detach().clone()))
+    l2, worst = digest_global_rel_l2(named, g, "gl.", skip=ZERO_GRAD_KEYS)
+    assert l2 <= lin_tol, ("linear-functional grads", case["name"], l2, worst)
+    # (b) the harness loss (L1 + dynamic): sign() of the L1 term makes this one only loosely comparable
+    net.zero_grad(set_to_none=True)
+    sr = net(lq, dm, mk)
+    w = torch.ones(cfg["depthRangeNum"], device=device, requires_grad=True)
+    total, l_pix, l_dyn, per = O.total_loss(sr, gt, mk, w)
+    total.backward()
+    assert abs(l_pix.item() - float(g["l_pix"])) <= 2e-5
+    assert abs(l_dyn.item() - float(g["l_dyn"])) <= 2e-4
+    named = [(k, p.grad) for k, p in net.named_parameters() if k not in nograd]
+    l2b, worstb = digest_global_rel_l2(named, g, "g.", skip=ZERO_GRAD_KEYS)
+    assert l2b <= loss_tol, ("loss grads", case["name"], l2b, worstb)
+    return dict(fwd_err=err, dpsnr=dpsnr, lin_l2=l2, lin_worst=worst, loss_l2=l2b)
+
+
+def check_conv_variants(device, seed=0):
+    """dasr_conv2d_{fwd,epilogue_bwd,dgrad,wgrad} + weight pack vs torch autograd on random data."""
+    gen = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    cases = [  # cin, cout, k, stride, pad, transposed, act, ps_r, residual, H, W
+        (5, 8, 3, 1, 1, False, 0, 1, False, 7, 9), (5, 8, 3, 2, 1, False, 2, 1, False, 7, 9),
+        (5, 8, 3, 2, 1, False, 2, 1, False, 8, 10), (6, 4, 3, 2, 1, True, 2, 1, False, 5, 6),
+        (4, 16, 3, 1, 1, False, 2, 2, False, 6, 7), (4, 18, 3, 1, 1, False, 2, 3, False, 5, 4),
+        (8, 8, 3, 1, 1, False, 1, 1, True, 9, 9), (4, 3, 9, 1, 4, False, 0, 1, False, 11, 13),
+        (1, 16, 3, 1, 1, False, 1, 1, False, 6, 5), (64, 64, 3, 1, 1, False, 0, 1, False, 9, 33),
+        (32, 32, 3, 1, 1, False, 1, 1, True, 8, 34), (128, 128, 3, 1, 1, False, 0, 1, False, 5, 33),
+        (64, 256, 3, 1, 1, False, 2, 2, False, 6, 9), (32, 128, 3, 1, 1, False, 2, 2, False, 10, 35),
+    ]
+    worst = 0.0
+    for (cin, cout, k, stride, pad, tr, act, ps, res, H, W) in cases:
+        B = 2
+        x = rn(B, cin, H, W).requires_grad_(True)
+        wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+        v = rn(*wshape).requires_grad_(True)
+        g = (torch.rand(wshape[0], 1, 1, 1, generator=gen) + 0.5).requires_grad_(True)
+        b = rn(cout).requires_grad_(True)
+        w = torch._weight_norm(v, g, 0)
+        y = F.conv_transpose2d(x, w, b, stride=stride, padding=pad) if tr else \
+            F.conv2d(x, w, b, stride=stride, padding=pad)
+        r = None
+        if res:
+            r = rn(*y.shape).requires_grad_(True)
+            y = y + r
+        if act == 1:
+            y = F.relu(y)
+        if act == 2:
+            y = F.leaky_relu(y, 0.2)
+        if ps > 1:
+            y = F.pixel_shuffle(y, ps)
+        wgt = rn(*y.shape)
+        (y * wgt).sum().backward()
+        tape = Tape()
+        xv = Var(nhwc(x.detach()).to(device), True)
+        vv, gv, bv = (Var(t.detach().clone().to(device), True) for t in (v, g, b))
+        rv = Var(nhwc(r.detach()).to(device), True) if res else None
+        wv = graph.pack(tape, vv, gv, tr)
+        yv = graph.conv(tape, xv, wv, bv, stride=stride, pad=pad, transposed=tr, act=act, ps_r=ps, residual=rv)
+        errs = [rel_max(nchw(yv.data), y.detach())]
+        yv.grad = nhwc(wgt).to(device)
+        tape.backward()
+        errs += [rel_max(nchw(xv.grad), x.grad), rel_max(vv.grad, v.grad), rel_max(gv.grad, g.grad),
+                 rel_max(bv.grad, b.grad)]
+        if res:
+            errs.append(rel_max(nchw(rv.grad), r.grad))
+        tol = 2e-5 if cin * k * k < 600 else 1e-4
+        assert max(errs) <= tol, ((cin, cout, k, stride, pad, tr, act, ps, res, H, W), errs)
+        worst = max(worst, max(errs))
+    return worst
+
+
+def check_pixel_shuffle_bit_exact(device):
+    """The fused PixelShuffle store must reproduce nn.PixelShuffle's index map bit for bit."""
+    for r in (2, 3):
+        g = load("pixel_shuffle_r%d" % r)
+        B, Crr, H, W = (int(v) for v in g["src_shape"])
+        src = torch.arange(B * Crr * H * W, dtype=torch.float32).reshape(B, Crr, H, W)
+        # identity 1x1 convolution (w = I) routes the input through the conv epilogue unchanged
+        w = torch.eye(Crr).reshape(1, 1, Crr, Crr).contiguous().to(device)
+        y = ops.conv2d_fwd(nhwc(src).to(device), w, None, None, stride=1, pad=0, act=ops.ACT_NONE, ps_r=r)
+        out = nchw(y).cpu().numpy().astype(np.int32)
+        assert np.array_equal(out, g["out"]), r
+        # and the backward of the epilogue is the inverse permutation
+        dy = torch.arange(y.numel(), dtype=torch.float32).reshape(y.shape).to(device)
+        dconv = ops.conv2d_epilogue_bwd(dy, y, H, W, Crr, ops.ACT_NONE, r)
+        want = F.pixel_unshuffle(nchw(dy.cpu()), r)
+        assert torch.equal(nchw(dconv.cpu()), want)
+
+
+def check_sean_golden(device):
+    worst = 0.0
+    for case in SEAN_CASES:
+        if case["dtype"] != "float32":
+            continue
+        g = load("sean_" + case["name"])
+        B, C, K, L, H, W = (case[k] for k in ("B", "C", "K", "L", "H", "W"))
+        shapes = {"alpha_beta": (1,), "alpha_gamma": (1,), "A_i_j.weight": (K, K, 1, 1), "A_i_j.bias": (K,),
+                  "mlp_gamma_s.weight": (C, L, 3, 3), "mlp_gamma_s.bias": (C,), "mlp_beta_s.weight": (C, L, 3, 3),
+                  "mlp_beta_s.bias": (C,), "mlp_mask.0.weight": (2 * C, 1, 3, 3), "mlp_mask.0.bias": (2 * C,),
+                  "mlp_gamma_o.weight": (C, 2 * C, 3, 3), "mlp_gamma_o.bias": (C,),
+                  "mlp_beta_o.weight": (C, 2 * C, 3, 3), "mlp_beta_o.bias": (C,)}
+        sd = {k: torch.zeros(s) for k, s in shapes.items()}
+        synth.closed_form_fill_(sd.items())
+        x, dmap, dmask, st = sean_inputs(case, torch.float32)
+        # The reference SEAN normalises its input once (normalization.py:56); the fused kernel applies the
+        # closed form of TWO instance norms to a raw conv output.  Feed it a tensor whose first instance norm
+        # is the identity up to rounding:  x_in = IN(x)  (then IN(IN(x_in)) == the reference's IN(x_in)) ...
+        # that identity does not hold exactly, so compare through the oracle instead (pinned to the
+        # reference by tests/test_oracle_golden.py) and keep the golden file for the raw SEAN output check.
+        xi = F.instance_norm(x, eps=1e-5)
+        P = {"n." + k: Var(v.clone().to(device), True, "n." + k) for k, v in sd.items()}
+        sdo = {"n." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        cfg = O.make_cfg(depth_latent_ch=L, depthRangeNum=K)
+        xo = x.clone().requires_grad_(True)
+        sto = st.clone().requires_grad_(True)
+        ref = O.sean(sdo, "n", F.instance_norm(xo, eps=1e-5), dmap, dmask, sto, cfg)
+        wgt = torch.cos(torch.arange(ref.numel(), dtype=torch.float32) * 0.013).reshape(ref.shape)
+        (ref * wgt).sum().backward()
+        # golden pin of the oracle's SEAN on the same inputs (reference output)
+        assert np.abs(O.sean(sdo, "n", x, dmap, dmask, st, cfg).detach().numpy() - g["out"]).max() <= 2e-5
+        tape = Tape()
+        tv = Var(nhwc(x).to(device), True)
+        stv = Var(st.clone().to(device), True)
+        dv = Var(dmap.reshape(B, H, W, 1).contiguous().to(device))
+        ov = graph.sean(tape, P, "n", tv, dv, dmask.contiguous().to(device), stv, None, False,
+                        {"alpha_gamma": None, "alpha_beta": None})
+        errs = [rel_max(nchw(ov.data), ref.detach())]
+        ov.grad = nhwc(wgt).to(device)
+        tape.backward()
+        errs += [rel_max(nchw(tv.grad), xo.grad), rel_max(stv.grad, sto.grad)]
+        for k in sd:
+            errs.append(rel_max(P["n." + k].grad.reshape(sd[k].shape), sdo["n." + k].grad))
+        assert max(errs) <= 2e-4, (case["name"], errs)
+        worst = max(worst, max(errs))
+        del xi
+    return worst
+
+
+def check_region_pool(device):
+    for name, (feat, mask) in pool_inputs().items():
+        g = load("pool_" + name)
+        tape = Tape()
+        fv = Var(nhwc(feat).to(device), True)
+        out = graph.region_pool(tape, fv, mask.contiguous().to(device))
+        assert np.abs(out.data.cpu().numpy() - g["out"]).max() <= 2e-6, name
+        wgt = torch.sin(torch.arange(out.data.numel(), dtype=torch.float32) * 0.7).reshape(out.data.shape)
+        out.grad = wgt.to(device)
+        tape.backward()
+        assert np.abs(nchw(fv.grad).cpu().numpy() - g["dfeat"]).max() <= 2e-6, name
+    g = load("pool_same_empty")
+    assert np.all(g["out"][:, 4] == 0)
+
+
+def check_blocks(device):
+    """Depth_Residual_Block_Mask and Classic_Residual_Block vs the reference vectors."""
+    g = load("dgb_block")
+    x, dmap, dmask, st = block_inputs()
+    B, C, H, W = x.shape
+    names = ["norm1." + k for k in _sean_keys()] + ["norm2." + k for k in _sean_keys()] + \
+        ["conv1.0.weight", "conv1.0.bias", "conv2.0.weight", "conv2.0.bias"]
+    shapes = _dgb_shapes(64, 10, 32)
+    sd = {k: torch.zeros(shapes[k]) for k in names}
+    synth.closed_form_fill_(sd.items())
+    P = {"b." + k: Var(v.to(device), True, "b." + k) for k, v in sd.items()}
+    tape = Tape()
+    xv = Var(nhwc(x).to(device), True)
+    stv = Var(st.clone().to(device), True)
+    dv = Var(dmap.reshape(B, H, W, 1).contiguous().to(device))
+    out = graph.depth_block(tape, P, "b", xv, dv, dmask.contiguous().to(device), stv, {})
+    assert rel_max(nchw(out.data), g["out"]) <= 1e-5
+    wgt = torch.cos(torch.arange(out.data.numel(), dtype=torch.float32) * 0.011).reshape(B, C, H, W)
+    out.grad = nhwc(wgt).to(device)
+    tape.backward()
+    assert rel_max(nchw(xv.grad), g["dx"]) <= 5e-4
+    assert rel_max(stv.grad, g["dst"]) <= 5e-4
+    named = [(k, P["b." + k].grad) for k in names]
+    l2, worst = digest_global_rel_l2(named, g, "g.", skip=ZERO_GRAD_KEYS)
+    assert l2 <= 5e-4, (l2, worst)
+
+    g = load("classic_block")
+    sd = {"block.0.bias": torch.zeros(32), "block.0.weight_g": torch.zeros(32, 1, 1, 1),
+          "block.0.weight_v": torch.zeros(32, 32, 3, 3), "block.2.bias": torch.zeros(32),
+          "block.2.weight_g": torch.zeros(32, 1, 1, 1), "block.2.weight_v": torch.zeros(32, 32, 3, 3)}
+    synth.closed_form_fill_(sd.items())
+    P = {"c." + k: Var(v.to(device), True, "c." + k) for k, v in sd.items()}
+    tape = Tape()
+    xc = block_inputs()[0][:, :32].contiguous()
+    xv = Var(nhwc(xc).to(device), True)
+    out = graph.classic_block(tape, P, "c", xv)
+    assert rel_max(nchw(out.data), g["out"]) <= 1e-5
+    wgt = torch.cos(torch.arange(out.data.numel(), dtype=torch.float32) * 0.011).reshape(xc.shape)
+    out.grad = nhwc(wgt).to(device)
+    tape.backward()
+    assert rel_max(nchw(xv.grad), g["dx"]) <= 1e-4
+    l2, worst = digest_global_rel_l2([(k, P["c." + k].grad) for k in sd], g, "g.")
+    assert l2 <= 1e-4, (l2, worst)
+
+
+def _sean_keys():
+    return ["alpha_beta", "alpha_gamma", "A_i_j.weight", "A_i_j.bias", "mlp_gamma_s.weight", "mlp_gamma_s.bias",
+            "mlp_beta_s.weight", "mlp_beta_s.bias", "mlp_mask.0.weight", "mlp_mask.0.bias", "mlp_gamma_o.weight",
+            "mlp_gamma_o.bias", "mlp_beta_o.weight", "mlp_beta_o.bias"]
+
+
+def _dgb_shapes(C, K, L):
+    s = {}
+    for n in ("norm1.", "norm2."):
+        s.update({n + "alpha_beta": (1,), n + "alpha_gamma": (1,), n + "A_i_j.weight": (K, K, 1, 1),
+                  n + "A_i_j.bias": (K,), n + "mlp_gamma_s.weight": (C, L, 3, 3), n + "mlp_gamma_s.bias": (C,),
+                  n + "mlp_beta_s.weight": (C, L, 3, 3), n + "mlp_beta_s.bias": (C,),
+                  n + "mlp_mask.0.weight": (2 * C, 1, 3, 3), n + "mlp_mask.0.bias": (2 * C,),
+                  n + "mlp_gamma_o.weight": (C, 2 * C, 3, 3), n + "mlp_gamma_o.bias": (C,),
+                  n + "mlp_beta_o.weight": (C, 2 * C, 3, 3), n + "mlp_beta_o.bias": (C,)})
+    s.update({"conv1.0.weight": (C, C, 3, 3), "conv1.0.bias": (C,), "conv2.0.weight": (C, C, 3, 3),
+              "conv2.0.bias": (C,)})
+    return s
+
+
+def check_encoder_geometry(device):
+    """Encoder (ConvTranspose geometry: 128x160 -> 63x79 -> 32x40) for odd and even sizes."""
+    shapes_all = json.load(open(os.path.join(GOLDEN, "encoder_shapes.json")))
+    for (H, W) in [(16, 20), (17, 21), (18, 23)]:
+        g = load("encoder_%dx%d" % (H, W))
+        shp = {k[len("encoder."):]: v for k, v in O.param_shapes(O.make_cfg(depth_latent_ch=8)).items()
+               if k.startswith("encoder.")}
+        sd = {k: torch.zeros(s) for k, s in shp.items()}
+        synth.closed_form_fill_(sd.items())
+        P = {"encoder." + k: Var(v.to(device), False) for k, v in sd.items()}
+        lq, _, _, masks = synth.closed_form_batch(0, 1, H, W, 1)
+        tape = Tape(False)
+        x0 = Var(nhwc(lq).to(device))
+        L = ops.ACT_LRELU
+        e1 = graph.conv(tape, x0, graph._wn(tape, P, "encoder.layer1"), P["encoder.layer1.bias"], act=L)
+        e2 = graph.conv(tape, e1, graph._wn(tape, P, "encoder.layer2"), P["encoder.layer2.bias"], stride=2, act=L)
+        e3 = graph.conv(tape, e2, graph._wn(tape, P, "encoder.layer3"), P["encoder.layer3.bias"], stride=2, act=L)
+        e4 = graph.conv(tape, e3, graph._wn(tape, P, "encoder.layer4", True), P["encoder.layer4.bias"], stride=2,
+                        transposed=True, act=L)
+        e5 = graph.conv(tape, e4, graph._wn(tape, P, "encoder.layer5"), P["encoder.layer5.bias"], stride=2)
+        st = graph.region_pool(tape, e5, masks.contiguous().to(device))
+        exp = shapes_all["%dx%d" % (H, W)]
+        for got, want in zip((e1, e2, e3, e4, e5), exp[:5]):
+            b, hh, ww, c = got.data.shape
+            assert [b, c, hh, ww] == want, (got.data.shape, want)
+        assert np.abs(nchw(e1.data).cpu().numpy() - g["feat"]).max() <= 2e-6
+        assert np.abs(nchw(e5.data).cpu().numpy() - g["l5"]).max() <= 5e-6
+        assert np.abs(st.data.cpu().numpy() - g["vec"]).max() <= 5e-6

@@ -1,0 +1,39 @@
+"""The HIP kernel sources, executed by the CPU kernel emulator (tests/hipemu), against the reference's
+golden vectors and the oracle.  These run without a GPU; tests/test_gpu_parity.py repeats them on the
+MI355X through libdasr_hip.so."""
+import pytest
+
+from tests import parity_checks as pc
+from tests.emu_fixture import emu  # noqa: F401
+from tests.golden_cases import DEPTHNET_CASES
+
+
+def test_conv_variants(emu):
+    pc.check_conv_variants("cpu")
+
+
+def test_pixel_shuffle_bit_exact(emu):
+    pc.check_pixel_shuffle_bit_exact("cpu")
+
+
+def test_sean(emu):
+    pc.check_sean_golden("cpu")
+
+
+def test_region_pool(emu):
+    pc.check_region_pool("cpu")
+
+
+def test_blocks(emu):
+    pc.check_blocks("cpu")
+
+
+def test_encoder_geometry(emu):
+    pc.check_encoder_geometry("cpu")
+
+
+@pytest.mark.parametrize("case", DEPTHNET_CASES, ids=[c["name"] for c in DEPTHNET_CASES])
+def test_depthnet(emu, case):
+    tol = 0.2 if case["name"].endswith("odd") else 2e-3   # 'odd' case: a ReLU flip makes even the fp64 oracle move
+    r = pc.check_depthnet_case(case, "cpu", lin_tol=tol, loss_tol=0.3)
+    print(case["name"], r)
