@@ -29,6 +29,7 @@ extern "C" int dasr_conv2d_fwd(const float* x, const float* w, const float* bias
     if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
     if (ps_r < 1) ps_r = 1;
     if (ps_r > 1 && (Cout % (ps_r * ps_r)) != 0) return DASR_E_SHAPE;
+    if (conv_mfma_supported(g)) return conv_mfma_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
     return conv_direct_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
 }
 
@@ -50,13 +51,14 @@ extern "C" int dasr_conv2d_dgrad(const float* dconv, const float* w, float* dx, 
     ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
     int rc = check_geom(g);
     if (rc) return rc;
+    if (conv_mfma_dgrad_supported(g)) return conv_mfma_dgrad(g, dconv, w, dx, accumulate, stream);
     return conv_direct_dgrad(g, dconv, w, dx, accumulate, stream);
 }
 
 extern "C" size_t dasr_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
                                               int stride, int pad, int transposed) {
-    (void)B; (void)H; (void)W; (void)Cin; (void)Ho; (void)Wo; (void)Cout; (void)KH; (void)KW; (void)stride; (void)pad;
-    (void)transposed;
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    if (check_geom(g) == DASR_OK && conv_mfma_wgrad_supported(g)) return conv_mfma_wgrad_workspace(g);
     return 0;
 }
 
@@ -64,11 +66,16 @@ extern "C" int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw, 
                                  size_t workspace_bytes, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
                                  int KW, int stride, int pad, int transposed, void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(dw);
-    (void)workspace; (void)workspace_bytes;
     ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
     int rc = check_geom(g);
     if (rc) return rc;
-    rc = conv_direct_wgrad(g, x, dconv, dw, stream);
+    if (conv_mfma_wgrad_supported(g)) {
+        if (!workspace) return DASR_E_NULL;
+        if (workspace_bytes < conv_mfma_wgrad_workspace(g)) return DASR_E_WORKSPACE;
+        rc = conv_mfma_wgrad(g, x, dconv, dw, workspace, stream);
+    } else {
+        rc = conv_direct_wgrad(g, x, dconv, dw, stream);
+    }
     if (rc) return rc;
     if (dbias) rc = conv_colsum(dconv, dbias, (size_t)B * Ho * Wo, Cout, stream);
     return rc;

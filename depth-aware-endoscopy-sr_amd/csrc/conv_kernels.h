@@ -24,3 +24,13 @@ int conv_epilogue_bwd(const ConvGeom& g, const float* dy, const float* y, float*
 int conv_direct_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
 int conv_direct_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* stream);
 int conv_colsum(const float* m, float* out, size_t rows, int C, void* stream);
+
+// conv_mfma.hip (3x3, stride 1, pad 1, channel counts multiples of 16/32)
+bool conv_mfma_supported(const ConvGeom& g);
+bool conv_mfma_dgrad_supported(const ConvGeom& g);
+bool conv_mfma_wgrad_supported(const ConvGeom& g);
+int conv_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
+                  float* y, int act, int ps_r, void* stream);
+int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
+size_t conv_mfma_wgrad_workspace(const ConvGeom& g);
+int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream);

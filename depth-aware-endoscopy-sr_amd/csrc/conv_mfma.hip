@@ -1,0 +1,310 @@
+// conv_mfma.hip — 3x3 / stride 1 / pad 1 convolutions of the trunk as im2col-free implicit GEMMs on the
+// fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD), NHWC x HWIO.
+//
+//   forward : out[p, co]  = sum_{tap, ci} in[p + off(tap), ci] * W[tap][ci][co]       M = pixels, N = co, K = 9*Cin
+//   dgrad   : the same kernel run on dconv with the taps flipped and ci/co swapped      (WMODE = 1)
+//   wgrad   : dW[tap][ci][co] = sum_p in[p + off(tap), ci] * dconv[p, co]               M = ci,  N = co, K = pixels
+//
+// Forward / dgrad kernel.  Workgroup = 256 threads = 4 waves, output tile = 8 rows x 32 columns of pixels x
+// (32*NT) output channels.  Wave w owns tile rows 2w and 2w+1 (two 32-pixel M-tiles) x NT 32-channel N-tiles:
+// 2*NT accumulators of 16 VGPRs.  K loop: input channels in chunks of 16; per chunk the 10 x 34 input halo
+// tile (zero outside the image = the convolution's zero padding) and the 9 x (32*NT) x 16 weight slice are
+// staged in LDS with a pixel / channel stride of 20 floats, which makes every ds_read_b128 of a wave
+// conflict-free (MI355X_MICROARCH.md §LDS: 16 lanes x 16 B at stride 80 B hit 16 distinct 4-bank slots).
+// One ds_read_b128 feeds four K=2 MFMA steps: lane (i, h) holds channels 8q+4h .. 8q+4h+3 of pixel i (A) or
+// of output channel i (B), so MFMA step j contracts channel 8q+j on the lower half-wave and 8q+4+j on the
+// upper one — any K order is valid as long as A and B agree.
+// Epilogue: D fragment has the output channel on the lane (col = lane&31) and 16 pixels in registers, so each
+// store instruction writes two 128-byte runs; bias, residual, activation and the PixelShuffle index map are
+// applied there.
+#include "dasr_common.h"
+#include "conv_kernels.h"
+
+#define CM_TH 8
+#define CM_TW 32
+#define CM_CK 16
+#define CM_CKP 20
+#define CM_HALO_W (CM_TW + 2)
+#define CM_HALO_H (CM_TH + 2)
+
+struct ConvMfmaArgs {
+    const float* x;         // [B,H,W,Cin]
+    const float* w;         // WMODE 0: HWIO [9][Cin][Cout];  WMODE 1: HWIO of the forward conv, [9][Cout][Cin]
+    const float* bias;      // [Cout] or null
+    const float* residual;  // [B,H,W,Cout] or null
+    float* y;
+    int B, H, W, Cin, Cout;
+    int act, ps_r, accumulate;
+};
+
+template <int NT, int WMODE>
+__global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
+    DASR_DYN_SMEM(smem);
+    float* sIn = (float*)smem;                                // [HALO_H*HALO_W][CKP]
+    float* sW = sIn + CM_HALO_H * CM_HALO_W * CM_CKP;         // [9][32*NT][CKP]
+    constexpr int NTILE = 32 * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (a.W + CM_TW - 1) / CM_TW;
+    const int x0 = (blockIdx.x % tiles_x) * CM_TW, y0 = (blockIdx.x / tiles_x) * CM_TH;
+    const int b = blockIdx.y, n0 = blockIdx.z * NTILE;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CM_CK) {
+        __syncthreads();
+        // ---- stage the input halo tile: one float4 (4 channels) per thread-iteration
+        for (int idx = tid; idx < CM_HALO_H * CM_HALO_W * 4; idx += 256) {
+            int pix = idx >> 2, q4 = idx & 3;
+            int gy = y0 + pix / CM_HALO_W - 1, gx = x0 + pix % CM_HALO_W - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
+            *(float4*)(sIn + pix * CM_CKP + 4 * q4) = v;
+        }
+        // ---- stage the weight slice as [tap][n][k]
+        if (WMODE == 0) {
+            // source HWIO [tap][ci][co]: co contiguous -> transpose into [n = co][k = ci]
+            for (int idx = tid; idx < 9 * CM_CK * NTILE; idx += 256) {
+                int nl = idx % NTILE, kl = (idx / NTILE) % CM_CK, tap = idx / (NTILE * CM_CK);
+                sW[(tap * NTILE + nl) * CM_CKP + kl] = a.w[((size_t)tap * a.Cin + c0 + kl) * a.Cout + n0 + nl];
+            }
+        } else {
+            // dgrad: this kernel's (Cin, Cout) = the forward conv's (Cout_f, Cin_f); source HWIO_f [tap][n][k]
+            // with k contiguous; taps flipped (tap' = 8 - tap)
+            for (int idx = tid; idx < 9 * NTILE * 4; idx += 256) {
+                int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
+                float4 v = *(const float4*)(a.w + ((size_t)(8 - tap) * a.Cout + n0 + nl) * a.Cin + c0 + 4 * q4);
+                *(float4*)(sW + (tap * NTILE + nl) * CM_CKP + 4 * q4) = v;
+            }
+        }
+        __syncthreads();
+        // ---- 9 taps x 16 channels = 72 K=2 steps per accumulator
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float4 A[2], Bf[NT];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    A[m] = *(const float4*)(sIn + ((2 * wv + m + dy) * CM_HALO_W + li + dx) * CM_CKP + 8 * q + 4 * lh);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    Bf[n] = *(const float4*)(sW + (tap * NTILE + 32 * n + li) * CM_CKP + 8 * q + 4 * lh);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].x, Bf[n].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].y, Bf[n].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].z, Bf[n].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].w, Bf[n].w, acc[m][n], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // ---- epilogue
+    const int rr = a.ps_r * a.ps_r;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int gy = y0 + 2 * wv + m;
+        if (gy >= a.H) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n0 + 32 * n + li;
+            const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (gx >= a.W) continue;
+                const size_t pidx = (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co;
+                float v = acc[m][n][r] + bv;
+                if (a.residual) v += a.residual[pidx];
+                v = dasr_act(v, a.act);
+                size_t o = pidx;
+                if (a.ps_r > 1) {
+                    int c = co / rr, i = (co / a.ps_r) % a.ps_r, j = co % a.ps_r;
+                    o = (((size_t)b * a.H * a.ps_r + (size_t)gy * a.ps_r + i) * ((size_t)a.W * a.ps_r) +
+                         (size_t)gx * a.ps_r + j) * (a.Cout / rr) + c;
+                }
+                if (a.accumulate) v += a.y[o];
+                a.y[o] = v;
+            }
+        }
+    }
+}
+
+static size_t conv_mfma_lds(int NT) {
+    return sizeof(float) * (size_t)(CM_HALO_H * CM_HALO_W * CM_CKP + 9 * 32 * NT * CM_CKP);
+}
+
+bool conv_mfma_supported(const ConvGeom& g) {
+    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin % CM_CK) == 0 &&
+           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+}
+
+template <int WMODE>
+static int launch_conv_mfma(ConvMfmaArgs& a, void* stream) {
+    int tiles = ((a.W + CM_TW - 1) / CM_TW) * ((a.H + CM_TH - 1) / CM_TH);
+    if ((a.Cout % 64) == 0) {
+        DASR_LAUNCH((k_conv3x3_mfma<2, WMODE>), dim3(tiles, a.B, a.Cout / 64), dim3(256), conv_mfma_lds(2), stream, a);
+    } else {
+        DASR_LAUNCH((k_conv3x3_mfma<1, WMODE>), dim3(tiles, a.B, a.Cout / 32), dim3(256), conv_mfma_lds(1), stream, a);
+    }
+    DASR_RETURN_LAUNCH_STATUS();
+}
+
+int conv_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
+                  float* y, int act, int ps_r, void* stream) {
+    ConvMfmaArgs a{x, w, bias, residual, y, g.B, g.H, g.W, g.Cin, g.Cout, act, ps_r, 0};
+    return launch_conv_mfma<0>(a, stream);
+}
+
+// dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * W[tap][ci][co]: a 3x3 conv of dconv (channels Cout) to Cin
+int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream) {
+    ConvMfmaArgs a{dconv, w, nullptr, nullptr, dx, g.B, g.H, g.W, g.Cout, g.Cin, DASR_ACT_NONE, 1, accumulate};
+    return launch_conv_mfma<1>(a, stream);
+}
+bool conv_mfma_dgrad_supported(const ConvGeom& g) {
+    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cout % CM_CK) == 0 &&
+           (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// Workgroup = 4 waves, owns a (32*MT) x (32*NTW) block of (ci, co) for all 9 taps and walks a strip of
+// 4 x 32 pixel tiles with the accumulators resident; K = pixels, two per MFMA step (h = lane>>5 picks the
+// pixel of the pair).  A fragment: lane i reads channel ci0+i of pixel (p + off(tap)) -> 32 consecutive
+// floats per half-wave (conflict-free ds_read_b32); B fragment likewise from the dconv tile.  Each strip
+// writes its partial dW as a slab; k_wgrad_reduce sums the slabs in a fixed order (bitwise reproducible).
+#define WG_TH 4
+#define WG_TW 32
+
+struct WgradArgs {
+    const float* x;      // [B,H,W,Cin]
+    const float* dy;     // [B,H,W,Cout]
+    float* slabs;        // [P][9][Cin][Cout]
+    int B, H, W, Cin, Cout;
+    int P, ntiles;
+};
+
+template <int MT, int NTW>
+__global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int CIG = 32 * MT, COG = 32 * NTW;
+    constexpr int G = 4 / (MT * NTW);           // wave groups sharing one (mt, nt) pair, splitting the taps
+    constexpr int NACC = (9 + G - 1) / G;
+    float* sX = (float*)smem;                                   // [(TH+2)*(TW+2)][CIG]
+    float* sD = sX + (WG_TH + 2) * (WG_TW + 2) * CIG;           // [TH*TW][COG]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int pair = wv % (MT * NTW), grp = wv / (MT * NTW);
+    const int mt = pair / NTW, nt = pair % NTW;
+    const int cgroups = a.Cout / COG;
+    const int ci0 = (blockIdx.x / cgroups) * CIG, co0 = (blockIdx.x % cgroups) * COG;
+    const int tiles_x = (a.W + WG_TW - 1) / WG_TW, tiles_y = (a.H + WG_TH - 1) / WG_TH;
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx * WG_TW, y0 = ty * WG_TH;
+        __syncthreads();
+        for (int idx = tid; idx < (WG_TH + 2) * (WG_TW + 2) * (CIG / 4); idx += 256) {
+            int c4 = idx % (CIG / 4), pix = idx / (CIG / 4);
+            int gy = y0 + pix / (WG_TW + 2) - 1, gx = x0 + pix % (WG_TW + 2) - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
+            *(float4*)(sX + pix * CIG + 4 * c4) = v;
+        }
+        for (int idx = tid; idx < WG_TH * WG_TW * (COG / 4); idx += 256) {
+            int c4 = idx % (COG / 4), pix = idx / (COG / 4);
+            int gy = y0 + pix / WG_TW, gx = x0 + pix % WG_TW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < a.H && gx < a.W)
+                v = *(const float4*)(a.dy + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * c4);
+            *(float4*)(sD + pix * COG + 4 * c4) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < WG_TH * WG_TW / 2; ++s) {
+            const int py = s / (WG_TW / 2), px = 2 * (s % (WG_TW / 2)) + lh;
+            const float bv = sD[(py * WG_TW + px) * COG + 32 * nt + li];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap % G != grp) continue;
+                const int dy = tap / 3, dx = tap % 3;
+                const float av = sX[((py + dy) * (WG_TW + 2) + px + dx) * CIG + 32 * mt + li];
+                acc[tap / G] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap / G], 0, 0, 0);
+            }
+        }
+    }
+    float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap % G != grp) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int ci = ci0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = acc[tap / G][r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, size_t n,
+                                                      int P) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int p = 0; p < P; ++p) acc += slabs[(size_t)p * n + i];
+        dw[i] = acc;
+    }
+}
+
+bool conv_mfma_wgrad_supported(const ConvGeom& g) {
+    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin % 32) == 0 &&
+           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+}
+static void wgrad_plan(const ConvGeom& g, int& MT, int& NTW, int& groups, int& ntiles, int& P) {
+    MT = (g.Cin % 64) == 0 ? 2 : 1;
+    NTW = (g.Cout % 64) == 0 ? 2 : 1;
+    groups = (g.Cin / (32 * MT)) * (g.Cout / (32 * NTW));
+    ntiles = g.B * ((g.H + WG_TH - 1) / WG_TH) * ((g.W + WG_TW - 1) / WG_TW);
+    P = 1024 / groups;
+    if (P < 1) P = 1;
+    if (P > ntiles) P = ntiles;
+}
+size_t conv_mfma_wgrad_workspace(const ConvGeom& g) {
+    int MT, NTW, groups, ntiles, P;
+    wgrad_plan(g, MT, NTW, groups, ntiles, P);
+    return sizeof(float) * (size_t)P * 9 * g.Cin * g.Cout;
+}
+int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream) {
+    int MT, NTW, groups, ntiles, P;
+    wgrad_plan(g, MT, NTW, groups, ntiles, P);
+    WgradArgs a{x, dconv, (float*)workspace, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
+    size_t lds = sizeof(float) * (size_t)((WG_TH + 2) * (WG_TW + 2) * 32 * MT + WG_TH * WG_TW * 32 * NTW);
+    dim3 grid(groups, P);
+    if (MT == 2 && NTW == 2) {
+        DASR_LAUNCH((k_conv3x3_wgrad_mfma<2, 2>), grid, dim3(256), lds, stream, a);
+    } else if (MT == 2 && NTW == 1) {
+        DASR_LAUNCH((k_conv3x3_wgrad_mfma<2, 1>), grid, dim3(256), lds, stream, a);
+    } else if (MT == 1 && NTW == 2) {
+        DASR_LAUNCH((k_conv3x3_wgrad_mfma<1, 2>), grid, dim3(256), lds, stream, a);
+    } else {
+        DASR_LAUNCH((k_conv3x3_wgrad_mfma<1, 1>), grid, dim3(256), lds, stream, a);
+    }
+    size_t n = (size_t)9 * g.Cin * g.Cout;
+    DASR_LAUNCH(k_wgrad_reduce, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, (const float*)workspace, dw, n, P);
+    DASR_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,154 @@
+"""Training / test harness around DepthNet — the counterpart of the reference's model wrapper.
+
+Reproduces what ``F_Model_depthCond`` does for the shipped ymls
+(codes/models/F_model_depthCond.py:87-122,146-192,228-234; codes/train.py:179-199):
+L1 pixel loss (weight 1) + dynamic depth-aware smooth-L1 loss (weight 10, 10 trainable region
+weights, codes/models/modules/mask_loss.py:44-90), Adam(lr 1e-3, betas (0.9, 0.99), wd 0) over the
+generator's parameters plus the loss weights, CosineAnnealingLR_Restart stepped BEFORE the optimiser
+(codes/models/lr_scheduler.py:34-62).  Losses and optimiser stay PyTorch (north_star); the generator
+forward/backward is the HIP path.
+
+Data parallel: one process per GPU (torchrun), ``torch.distributed`` backend ``nccl`` (= RCCL over
+xGMI) on the GPU box, ``gloo`` in CPU tests.  The net itself is communication-free (instance norm is
+per-sample); per step there is ONE flat gradient all-reduce (14.8 M fp32 = 59 MB for the x8 net, plus
+the 10 loss weights), and the 2K numerator/denominator scalars of the dynamic loss are all-reduced so
+that the loss is the GLOBAL ratio the reference's default nn.DataParallel path computes on GPU0
+(SURVEY.md §8e).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def cosine_restart_lr(step, base_lr=1e-3, T_period=(20000, 20000, 20000, 20000),
+                      restarts=(20000, 40000, 60000), weights=(1, 1, 1), eta_min=1e-7):
+    """Learning rate after ``step`` calls of CosineAnnealingLR_Restart.step()
+    (closed form of the recursion in codes/models/lr_scheduler.py:46-62)."""
+    last_restart, T, w = 0, T_period[0], 1.0
+    for j, r in enumerate(restarts):
+        if step >= r:
+            last_restart, T, w = r, T_period[j + 1], weights[j]
+    return eta_min + (base_lr * w - eta_min) * (1 + math.cos(math.pi * (step - last_restart) / T)) / 2
+
+
+class DynamicMaskLoss(torch.nn.Module):
+    """dynamic_weight_mask_loss with the 'smoothl1' criterion (mask_loss.py:44-90).
+
+    ``smooth_l1(m*sr, m*hr)`` only sees the difference ``m*(sr-hr)``, so each region costs one masked
+    pass over ``sr-hr``.  With a process group the region sums are made global before the division.
+    """
+
+    def __init__(self, num_regions=10, weight=10.0):
+        super().__init__()
+        self.l_mask_w = weight
+        self.trainable_weight = torch.nn.Parameter(torch.ones(num_regions))
+
+    def forward(self, sr, hr, mask_list, group=None):
+        K = mask_list.shape[1]
+        assert K == self.trainable_weight.numel(), "The number of trainable parameters for dynamic loss is not enought."
+        sm = F.softmax(self.trainable_weight, dim=0)
+        diff = sr - hr
+        nums, dens = [], []
+        for i in range(K):
+            m = F.interpolate(mask_list[:, i:i + 1], size=sr.shape[2:], mode="nearest")
+            nums.append(F.smooth_l1_loss(m * diff, torch.zeros_like(diff), reduction="none").sum())
+            dens.append(3.0 * m.sum())
+        num, den = torch.stack(nums), torch.stack(dens)
+        world = 1
+        if group is not None and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(group)
+        if world > 1:
+            gden = den.detach().clone()
+            gnum = num.detach().clone()
+            torch.distributed.all_reduce(gden, group=group)
+            torch.distributed.all_reduce(gnum, group=group)
+            # value = global ratio; gradient: this rank's numerator over the global denominator, times world so
+            # that the later gradient AVERAGE over ranks equals the gradient of the global loss
+            local = num / gden * world
+            per = gnum / gden
+            per = per + (local - local.detach())
+        else:
+            per = num / den
+        weighted = sm * per
+        return list(per.unbind(0)), list(weighted.unbind(0)), weighted.sum() * self.l_mask_w, sm
+
+
+class Trainer:
+    """feed_data / optimize_parameters / test of the reference wrapper, for one DepthNet."""
+
+    def __init__(self, net, num_regions=10, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.0, pixel_weight=1.0,
+                 dynamic_weight=10.0, group=None, T_period=(20000,) * 4, restarts=(20000, 40000, 60000),
+                 restart_weights=(1, 1, 1), eta_min=1e-7):
+        self.net = net
+        self.group = group
+        self.world = torch.distributed.get_world_size(group) if (group is not None or (
+            torch.distributed.is_available() and torch.distributed.is_initialized())) else 1
+        device = next(net.parameters()).device
+        self.dynamic_loss = DynamicMaskLoss(num_regions, dynamic_weight).to(device)
+        self.l_pix_w = pixel_weight
+        self.params = [p for p in net.parameters() if p.requires_grad] + list(self.dynamic_loss.parameters())
+        self.base_lr = lr
+        self.optimizer = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay, betas=betas)
+        self.sched = dict(T_period=T_period, restarts=restarts, weights=restart_weights, eta_min=eta_min)
+        self.step_count = 0
+        self.log = {}
+        self._flat = None
+
+    def update_learning_rate(self):
+        self.step_count += 1                       # scheduler.step() comes first (codes/train.py:194)
+        lr = cosine_restart_lr(self.step_count, self.base_lr, **self.sched)
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+        return lr
+
+    def _allreduce_grads(self):
+        """One flat all-reduce (sum, then / world).  Parameters that never receive a gradient
+        (the constructed-but-unused block ``depth-residual{nb-2}``) are skipped on
+        every rank alike, so the flat layout is identical everywhere."""
+        if self.world <= 1:
+            return
+        with_grad = [p for p in self.params if p.grad is not None]
+        n = sum(p.grad.numel() for p in with_grad)
+        if self._flat is None or self._flat.numel() != n:
+            self._flat = torch.empty(n, dtype=torch.float32, device=with_grad[0].device)
+        off = 0
+        for p in with_grad:
+            k = p.grad.numel()
+            self._flat[off:off + k].copy_(p.grad.reshape(-1))
+            off += k
+        torch.distributed.all_reduce(self._flat, group=self.group)
+        self._flat.div_(self.world)
+        off = 0
+        for p in with_grad:
+            k = p.grad.numel()
+            p.grad.copy_(self._flat[off:off + k].view_as(p.grad))
+            off += k
+
+    def optimize_parameters(self, lq, gt, depth, masks):
+        self.update_learning_rate()
+        self.optimizer.zero_grad(set_to_none=True)
+        sr = self.net(lq, depth, masks)
+        l_pix = self.l_pix_w * F.l1_loss(sr, gt)
+        per, weighted, l_dyn, sm = self.dynamic_loss(sr, gt, masks, self.group if self.world > 1 else None)
+        total = l_pix + l_dyn
+        total.backward()
+        self._allreduce_grads()
+        self.optimizer.step()
+        self.log = {"l_all": total.detach(), "l_pix": l_pix.detach(), "l_dynamic": l_dyn.detach()}
+        return self.log
+
+    @torch.no_grad()
+    def test(self, lq, depth, masks):
+        self.net.eval()
+        sr = self.net(lq, depth, masks)
+        self.net.train()
+        return sr
+
+
+def calculate_psnr(img1, img2):
+    """PSNR on [0,255] images (codes/utils/util.py:646-653)."""
+    mse = torch.mean((img1.double() - img2.double()) ** 2).item()
+    if mse == 0:
+        return float("inf")
+    return 20 * math.log10(255.0 / math.sqrt(mse))

@@ -1,0 +1,56 @@
+"""GPU parity tests: the same checks as tests/test_hip_path_emu.py, through libdasr_hip.so on the MI355X."""
+import os
+
+import pytest
+import torch
+
+from tests import parity_checks as pc
+from tests.golden_cases import DEPTHNET_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def device_lib():
+    from dasr_amd import _lib
+    os.environ.pop("DASR_HIPEMU_LIB", None)
+    _lib.reset_for_tests()
+    assert torch.cuda.is_available()
+    assert _lib.is_device_build()
+    yield
+
+
+def test_conv_variants():
+    pc.check_conv_variants("cuda")
+
+
+def test_pixel_shuffle_bit_exact():
+    pc.check_pixel_shuffle_bit_exact("cuda")
+
+
+def test_sean():
+    pc.check_sean_golden("cuda")
+
+
+def test_region_pool():
+    pc.check_region_pool("cuda")
+
+
+def test_blocks():
+    pc.check_blocks("cuda")
+
+
+def test_encoder_geometry():
+    pc.check_encoder_geometry("cuda")
+
+
+@pytest.mark.parametrize("case", DEPTHNET_CASES, ids=[c["name"] for c in DEPTHNET_CASES])
+def test_depthnet(case):
+    tol = 0.2 if case["name"].endswith("odd") else 5e-3
+    r = pc.check_depthnet_case(case, "cuda", lin_tol=tol, loss_tol=0.3)
+    print(case["name"], r)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
