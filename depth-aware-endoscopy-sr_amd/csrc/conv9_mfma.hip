@@ -1,0 +1,291 @@
+// conv9_mfma.hip — the generator's output convolution: 9x9, pad 4, Cin = 32 -> Cout = 3 at HR resolution
+// (reference: conv_output, sftmd_arch.py:910,948), forward / dgrad / wgrad on the fp32 matrix cores.
+//
+// With only 3 output channels a plain implicit GEMM (N = Cout) would use 3/32 of an MFMA tile.  Instead
+// one kernel axis is folded into N:
+//   forward:  P[q][(kw,co)] = sum_{kh,ci} x[q.y+kh-4, q.x][ci] * w[kh][kw][ci][co]        M = pixels q, N = 27, K = 288
+//             y[p][co]      = sum_kw P[(p.y, p.x+kw-4)][(kw,co)]                            (9-term shift-add via LDS)
+//   dgrad:    dx[q][ci]     = sum_kh sum_{k'} dyrow(q.y-kh+4)[3*(q.x-4) + k'] * Wd[kh][k'][ci]   M = pixels, N = 32, K = 9*28
+//             with k' = 3*(8-kw) + co running over the 27 consecutive floats of the 3-channel dy row
+//   wgrad:    dW[kh][(8-kw)*3+co][ci] = sum_q x[q][ci] * dyrow(q.y-kh+4)[3*q.x + n']      M = ci, N = 27, K = pixels
+// so every MFMA runs at 27/32 (fwd, wgrad) or 27/28 (dgrad) useful width.  dy has 3 channels, so its
+// haloed tile is tiny (14 KB) and consecutive lanes read it at a 3-float stride (conflict-free: gcd(3,32)=1).
+#include "dasr_common.h"
+#include "conv_kernels.h"
+
+#define C9_TH 8           // tile rows
+#define C9_TQ 64          // tile columns (forward: includes the 8-column halo; 56 outputs per tile)
+#define C9_CK 16
+#define C9_CKP 20
+#define C9_PST 28         // P row stride (27 used)
+#define C9_DYW ((C9_TQ + 8) * 3 + 8)   // dy tile row stride in floats: 72 px * 3 ch + pad
+
+struct Conv9Args {
+    const float* x;      // fwd/wgrad: [B,H,W,Cin] ; dgrad: unused
+    const float* w;      // HWIO [9][9][Cin][Cout]
+    const float* bias;   // fwd
+    const float* dy;     // dgrad/wgrad: [B,H,W,Cout]
+    float* out;          // fwd: y [B,H,W,Cout]; dgrad: dx [B,H,W,Cin]; wgrad: slabs
+    int B, H, W, Cin, Cout;
+    int accumulate, P, ntiles;
+};
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ void __launch_bounds__(256) k_conv9x9_fwd_mfma(Conv9Args a) {
+    DASR_DYN_SMEM(smem);
+    float* sIn = (float*)smem;                                    // [16][64][CKP]  (later: P [8][64][PST])
+    float* sW = sIn + (C9_TH + 8) * C9_TQ * C9_CKP;               // [9][32][CKP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int TWO = C9_TQ - 8;
+    const int tiles_x = (a.W + TWO - 1) / TWO;
+    const int x0 = (blockIdx.x % tiles_x) * TWO, y0 = (blockIdx.x / tiles_x) * C9_TH, b = blockIdx.y;
+    const int NN = 9 * a.Cout;   // <= 27
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += C9_CK) {
+        __syncthreads();
+        for (int idx = tid; idx < (C9_TH + 8) * C9_TQ * 4; idx += 256) {
+            int q4 = idx & 3, pix = idx >> 2;
+            int gy = y0 - 4 + pix / C9_TQ, gx = x0 - 4 + pix % C9_TQ;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
+            *(float4*)(sIn + pix * C9_CKP + 4 * q4) = v;
+        }
+        for (int idx = tid; idx < 9 * 32 * C9_CK; idx += 256) {
+            int k = idx % C9_CK, n = (idx / C9_CK) % 32, kh = idx / (C9_CK * 32);
+            float v = 0.f;
+            if (n < NN) {
+                int kw = n / a.Cout, co = n % a.Cout;
+                v = a.w[(((size_t)kh * 9 + kw) * a.Cin + c0 + k) * a.Cout + co];
+            }
+            sW[(kh * 32 + n) * C9_CKP + k] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kh = 0; kh < 9; ++kh) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 Bf = *(const float4*)(sW + (kh * 32 + li) * C9_CKP + 8 * q + 4 * lh);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r = 2 * wv + (t >> 1), half = t & 1;
+                    const float4 A = *(const float4*)(sIn + ((r + kh) * C9_TQ + 32 * half + li) * C9_CKP + 8 * q + 4 * lh);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, Bf.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, Bf.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, Bf.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, Bf.w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* sP = sIn;   // [8][64][PST]
+    if (li < C9_PST) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = 2 * wv + (t >> 1), half = t & 1;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                int qx = 32 * half + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                sP[(r * C9_TQ + qx) * C9_PST + li] = acc[t][g];
+            }
+        }
+    }
+    __syncthreads();
+    const int nout = C9_TH * TWO * a.Cout;
+    for (int idx = tid; idx < nout; idx += 256) {
+        int co = idx % a.Cout, ox = (idx / a.Cout) % TWO, r = idx / (a.Cout * TWO);
+        int gy = y0 + r, gx = x0 + ox;
+        if (gy >= a.H || gx >= a.W) continue;
+        float v = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int kw = 0; kw < 9; ++kw) v += sP[(r * C9_TQ + ox + kw) * C9_PST + kw * a.Cout + co];
+        a.out[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dgrad
+// tile: 8 rows x 64 columns of dx pixels x 32 input channels (blockIdx.z selects the 32-channel slice)
+__device__ __forceinline__ void c9_stage_dy(const Conv9Args& a, float* sDy, int b, int y0, int x0, int tid) {
+    // rows y0-4 .. y0+11, columns x0-4 .. x0+67, Cout channels interleaved; zero outside the image
+    const int rowf = (C9_TQ + 8) * a.Cout;
+    for (int idx = tid; idx < (C9_TH + 8) * C9_DYW; idx += 256) {
+        int f = idx % C9_DYW, ry = idx / C9_DYW;
+        float v = 0.f;
+        if (f < rowf) {
+            int gy = y0 - 4 + ry, gx = x0 - 4 + f / a.Cout, co = f % a.Cout;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = a.dy[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co];
+        }
+        sDy[idx] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
+    DASR_DYN_SMEM(smem);
+    float* sDy = (float*)smem;                       // [16][DYW]
+    float* sW = sDy + (C9_TH + 8) * C9_DYW;          // [9][28][32]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (a.W + C9_TQ - 1) / C9_TQ;
+    const int x0 = (blockIdx.x % tiles_x) * C9_TQ, y0 = (blockIdx.x / tiles_x) * C9_TH, b = blockIdx.y;
+    const int n0 = blockIdx.z * 32;
+    const int KK = 9 * a.Cout;   // 27 live k' per kh
+    c9_stage_dy(a, sDy, b, y0, x0, tid);
+    for (int idx = tid; idx < 9 * 28 * 32; idx += 256) {
+        int ci = idx & 31, kp = (idx >> 5) % 28, kh = idx / (28 * 32);
+        float v = 0.f;
+        if (kp < KK) {
+            int kw = 8 - kp / a.Cout, co = kp % a.Cout;
+            v = a.w[(((size_t)kh * 9 + kw) * a.Cin + n0 + ci) * a.Cout + co];
+        }
+        sW[idx] = v;
+    }
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll 1
+    for (int kh = 0; kh < 9; ++kh) {
+#pragma unroll 2
+        for (int s = 0; s < 14; ++s) {
+            const float bv = sW[(kh * 28 + 2 * s + lh) * 32 + li];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = 2 * wv + (t >> 1), half = t & 1;
+                const float av = sDy[(r - kh + 8) * C9_DYW + a.Cout * (32 * half + li) + 2 * s + lh];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int gy = y0 + 2 * wv + (t >> 1), half = t & 1;
+        if (gy >= a.H) continue;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int gx = x0 + 32 * half + (g & 3) + 8 * (g >> 2) + 4 * lh;
+            if (gx >= a.W) continue;
+            size_t o = (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + n0 + li;
+            float v = acc[t][g];
+            if (a.accumulate) v += a.out[o];
+            a.out[o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// Workgroup walks a strip of 8 x 64 pixel tiles; wave w owns tile rows 2w, 2w+1 and keeps nine
+// [32 ci x 32 n'] accumulators (one per kh).  Each wave writes its own slab [9][32][32];
+// k_conv9_wgrad_reduce sums slabs in a fixed order and un-folds n' = (8-kw)*3 + co.
+__global__ void __launch_bounds__(256) k_conv9x9_wgrad_mfma(Conv9Args a) {
+    DASR_DYN_SMEM(smem);
+    float* sX = (float*)smem;                         // [8][64][32]
+    float* sDy = sX + C9_TH * C9_TQ * 32;             // [16][DYW]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (a.W + C9_TQ - 1) / C9_TQ, tiles_y = (a.H + C9_TH - 1) / C9_TH;
+    const int ci0 = blockIdx.x * 32;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx * C9_TQ, y0 = ty * C9_TH;
+        __syncthreads();
+        for (int idx = tid; idx < C9_TH * C9_TQ * 8; idx += 256) {
+            int c4 = idx & 7, pix = idx >> 3;
+            int gy = y0 + pix / C9_TQ, gx = x0 + pix % C9_TQ;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < a.H && gx < a.W)
+                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
+            *(float4*)(sX + pix * 32 + 4 * c4) = v;
+        }
+        c9_stage_dy(a, sDy, b, y0, x0, tid);
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < 2 * C9_TQ / 2; ++s) {       // this wave's 2 rows x 64 columns, two pixels per step
+            const int r = 2 * wv + s / (C9_TQ / 2), qx = 2 * (s % (C9_TQ / 2)) + lh;
+            const float av = sX[(r * C9_TQ + qx) * 32 + li];
+#pragma unroll
+            for (int kh = 0; kh < 9; ++kh) {
+                const float bv = sDy[(r - kh + 8) * C9_DYW + a.Cout * qx + li];
+                acc[kh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh], 0, 0, 0);
+            }
+        }
+    }
+    float* slab = a.out + ((size_t)(blockIdx.y * 4 + wv) * gridDim.x + blockIdx.x) * (9 * 32 * 32);
+#pragma unroll
+    for (int kh = 0; kh < 9; ++kh)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            int ci = (g & 3) + 8 * (g >> 2) + 4 * lh;
+            slab[(kh * 32 + ci) * 32 + li] = acc[kh][g];
+        }
+}
+
+// dw[kh][kw][ci][co] = sum over slabs of slab[cig][kh][ci%32][(8-kw)*Cout+co]
+__global__ void __launch_bounds__(256) k_conv9_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                            int Cin, int Cout, int nslabs, int cgroups) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = 81 * Cin * Cout;
+    if (i >= n) return;
+    int co = i % Cout, ci = (i / Cout) % Cin, kw = (i / (Cout * Cin)) % 9, kh = i / (Cout * Cin * 9);
+    int np = (8 - kw) * Cout + co;
+    const float* p = slabs + (size_t)(ci / 32) * (9 * 32 * 32) + (kh * 32 + (ci & 31)) * 32 + np;
+    float acc = 0.f;
+    for (int s = 0; s < nslabs; ++s) acc += p[(size_t)s * cgroups * (9 * 32 * 32)];
+    dw[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------ host side
+bool conv9_mfma_supported(const ConvGeom& g) {
+    return g.KH == 9 && g.KW == 9 && g.stride == 1 && g.pad == 4 && !g.transposed && (g.Cin % 32) == 0 &&
+           g.Cout >= 1 && g.Cout <= 3 && g.H == g.Ho && g.W == g.Wo;
+}
+int conv9_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* stream) {
+    Conv9Args a{x, w, bias, nullptr, y, g.B, g.H, g.W, g.Cin, g.Cout, 0, 0, 0};
+    int TWO = C9_TQ - 8;
+    int tiles = ((g.W + TWO - 1) / TWO) * ((g.H + C9_TH - 1) / C9_TH);
+    size_t lds = sizeof(float) * (size_t)((C9_TH + 8) * C9_TQ * C9_CKP + 9 * 32 * C9_CKP);
+    DASR_LAUNCH(k_conv9x9_fwd_mfma, dim3(tiles, g.B), dim3(256), lds, stream, a);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream) {
+    Conv9Args a{nullptr, w, nullptr, dconv, dx, g.B, g.H, g.W, g.Cin, g.Cout, accumulate, 0, 0};
+    int tiles = ((g.W + C9_TQ - 1) / C9_TQ) * ((g.H + C9_TH - 1) / C9_TH);
+    size_t lds = sizeof(float) * (size_t)((C9_TH + 8) * C9_DYW + 9 * 28 * 32);
+    DASR_LAUNCH(k_conv9x9_dgrad_mfma, dim3(tiles, g.B, g.Cin / 32), dim3(256), lds, stream, a);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+static void conv9_wgrad_plan(const ConvGeom& g, int& ntiles, int& P) {
+    ntiles = g.B * ((g.H + C9_TH - 1) / C9_TH) * ((g.W + C9_TQ - 1) / C9_TQ);
+    P = 512 / (g.Cin / 32);
+    if (P > ntiles) P = ntiles;
+    if (P < 1) P = 1;
+}
+size_t conv9_mfma_wgrad_workspace(const ConvGeom& g) {
+    int ntiles, P;
+    conv9_wgrad_plan(g, ntiles, P);
+    return sizeof(float) * (size_t)P * 4 * (g.Cin / 32) * 9 * 32 * 32;
+}
+int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream) {
+    int ntiles, P;
+    conv9_wgrad_plan(g, ntiles, P);
+    Conv9Args a{x, nullptr, nullptr, dconv, (float*)workspace, g.B, g.H, g.W, g.Cin, g.Cout, 0, P, ntiles};
+    size_t lds = sizeof(float) * (size_t)(C9_TH * C9_TQ * 32 + (C9_TH + 8) * C9_DYW);
+    DASR_LAUNCH(k_conv9x9_wgrad_mfma, dim3(g.Cin / 32, P), dim3(256), lds, stream, a);
+    int n = 81 * g.Cin * g.Cout;
+    DASR_LAUNCH(k_conv9_wgrad_reduce, dim3(dasr_cdiv(n, 256)), dim3(256), 0, stream, (const float*)workspace, dw, g.Cin,
+                g.Cout, P * 4, g.Cin / 32);
+    DASR_RETURN_LAUNCH_STATUS();
+}

@@ -30,6 +30,8 @@ extern "C" int dasr_conv2d_fwd(const float* x, const float* w, const float* bias
     if (ps_r < 1) ps_r = 1;
     if (ps_r > 1 && (Cout % (ps_r * ps_r)) != 0) return DASR_E_SHAPE;
     if (conv_mfma_supported(g)) return conv_mfma_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
+    if (conv9_mfma_supported(g) && act == DASR_ACT_NONE && ps_r == 1 && !residual)
+        return conv9_mfma_fwd(g, x, w, bias, y, stream);
     return conv_direct_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
 }
 
@@ -52,6 +54,7 @@ extern "C" int dasr_conv2d_dgrad(const float* dconv, const float* w, float* dx, 
     int rc = check_geom(g);
     if (rc) return rc;
     if (conv_mfma_dgrad_supported(g)) return conv_mfma_dgrad(g, dconv, w, dx, accumulate, stream);
+    if (conv9_mfma_supported(g)) return conv9_mfma_dgrad(g, dconv, w, dx, accumulate, stream);
     return conv_direct_dgrad(g, dconv, w, dx, accumulate, stream);
 }
 
@@ -59,6 +62,7 @@ extern "C" size_t dasr_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int 
                                               int stride, int pad, int transposed) {
     ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
     if (check_geom(g) == DASR_OK && conv_mfma_wgrad_supported(g)) return conv_mfma_wgrad_workspace(g);
+    if (check_geom(g) == DASR_OK && conv9_mfma_supported(g)) return conv9_mfma_wgrad_workspace(g);
     return 0;
 }
 
@@ -73,6 +77,10 @@ extern "C" int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw, 
         if (!workspace) return DASR_E_NULL;
         if (workspace_bytes < conv_mfma_wgrad_workspace(g)) return DASR_E_WORKSPACE;
         rc = conv_mfma_wgrad(g, x, dconv, dw, workspace, stream);
+    } else if (conv9_mfma_supported(g)) {
+        if (!workspace) return DASR_E_NULL;
+        if (workspace_bytes < conv9_mfma_wgrad_workspace(g)) return DASR_E_WORKSPACE;
+        rc = conv9_mfma_wgrad(g, x, dconv, dw, workspace, stream);
     } else {
         rc = conv_direct_wgrad(g, x, dconv, dw, stream);
     }

@@ -34,3 +34,10 @@ int conv_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float
 int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
 size_t conv_mfma_wgrad_workspace(const ConvGeom& g);
 int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream);
+
+// conv9_mfma.hip (9x9, pad 4, Cin % 32 == 0, Cout <= 3: the output convolution)
+bool conv9_mfma_supported(const ConvGeom& g);
+int conv9_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* stream);
+int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
+size_t conv9_mfma_wgrad_workspace(const ConvGeom& g);
+int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream);

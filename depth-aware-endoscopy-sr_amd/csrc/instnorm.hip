@@ -1,44 +1,87 @@
 // instnorm.hip — per-(sample, channel) mean and biased variance of an NHWC tensor.
 // Reference: nn.InstanceNorm2d(affine=False) at sftmd_arch.py:811-820 and normalization.py:16-17,56.
-// Two passes over the (L2/MALL-resident) sample keep the variance free of E[x^2]-mean^2 cancellation.
+//
+// HBM-bound (one read of the tensor; the second pass of each chunk hits L1/L2).  The image is cut into
+// chunks of IN_CHUNK pixels; a workgroup (4 pixel lanes x 64 channel lanes, 256-byte coalesced rows)
+// computes the chunk's mean and its sum of squared deviations ABOUT THAT MEAN (no E[x^2]-mean^2
+// cancellation), and a second tiny kernel merges the chunks in a fixed order with Chan's formula, so
+// the result is bitwise reproducible.
 #include "dasr_common.h"
 
-__global__ void __launch_bounds__(256) k_instnorm_stats(const float* __restrict__ x, float* __restrict__ mean,
-                                                        float* __restrict__ var, int HW, int C) {
+#define IN_CHUNK 256
+
+__global__ void __launch_bounds__(256) k_instnorm_partial(const float* __restrict__ x, float* __restrict__ part, int HW,
+                                                          int C, int nchunks) {
     __shared__ float red[256];
     __shared__ float mu_s[64];
-    int b = blockIdx.x;
-    int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    int pl = threadIdx.x >> 6;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int c = blockIdx.z * 64 + (threadIdx.x & 63);
+    const int pl = threadIdx.x >> 6;
+    const int p0 = chunk * IN_CHUNK;
+    const int p1 = p0 + IN_CHUNK < HW ? p0 + IN_CHUNK : HW;
     const float* xb = x + (size_t)b * HW * C;
     float acc = 0.f;
     if (c < C)
-        for (int p = pl; p < HW; p += 4) acc += xb[(size_t)p * C + c];
+        for (int p = p0 + pl; p < p1; p += 4) acc += xb[(size_t)p * C + c];
     red[threadIdx.x] = acc;
     __syncthreads();
     if (pl == 0)
         mu_s[threadIdx.x] = (red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]) /
-                            (float)HW;
+                            (float)(p1 - p0);
     __syncthreads();
-    float mu = mu_s[threadIdx.x & 63];
+    const float mu = mu_s[threadIdx.x & 63];
     acc = 0.f;
     if (c < C)
-        for (int p = pl; p < HW; p += 4) {
+        for (int p = p0 + pl; p < p1; p += 4) {
             float d = xb[(size_t)p * C + c] - mu;
             acc = fmaf(d, d, acc);
         }
+    __syncthreads();
     red[threadIdx.x] = acc;
     __syncthreads();
     if (pl == 0 && c < C) {
-        mean[(size_t)b * C + c] = mu;
-        var[(size_t)b * C + c] =
-            (red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]) / (float)HW;
+        float m2 = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        size_t o = (((size_t)b * nchunks + chunk) * C + c) * 2;
+        part[o] = mu;
+        part[o + 1] = m2;
     }
 }
 
-extern "C" int dasr_instnorm_stats(const float* x, float* mean, float* var, int B, int HW, int C, void* stream) {
-    DASR_CHECK_PTR(x); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var);
+__global__ void k_instnorm_merge(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ var,
+                                 int HW, int C, int nchunks, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = i % C, b = i / C;
+    float cnt = 0.f, mu = 0.f, m2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        int p0 = k * IN_CHUNK;
+        float nb = (float)((p0 + IN_CHUNK < HW ? p0 + IN_CHUNK : HW) - p0);
+        size_t o = (((size_t)b * nchunks + k) * C + c) * 2;
+        float mb = part[o], m2b = part[o + 1];
+        float tot = cnt + nb, delta = mb - mu;
+        mu += delta * (nb / tot);
+        m2 += m2b + delta * delta * (cnt * nb / tot);
+        cnt = tot;
+    }
+    mean[i] = mu;
+    var[i] = m2 / (float)HW;
+}
+
+extern "C" size_t dasr_instnorm_stats_workspace(int B, int HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0) return 0;
+    size_t nchunks = ((size_t)HW + IN_CHUNK - 1) / IN_CHUNK;
+    return sizeof(float) * 2 * (size_t)B * nchunks * C;
+}
+
+extern "C" int dasr_instnorm_stats(const float* x, float* mean, float* var, void* workspace, size_t workspace_bytes,
+                                   int B, int HW, int C, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var); DASR_CHECK_PTR(workspace);
     DASR_CHECK_SHAPE(B > 0 && HW > 0 && C > 0);
-    DASR_LAUNCH(k_instnorm_stats, dim3(B, dasr_cdiv(C, 64)), dim3(256), 0, stream, x, mean, var, HW, C);
+    if (workspace_bytes < dasr_instnorm_stats_workspace(B, HW, C)) return DASR_E_WORKSPACE;
+    int nchunks = (HW + IN_CHUNK - 1) / IN_CHUNK;
+    float* part = (float*)workspace;
+    DASR_LAUNCH(k_instnorm_partial, dim3(nchunks, B, dasr_cdiv(C, 64)), dim3(256), 0, stream, x, part, HW, C, nchunks);
+    int n = B * C;
+    DASR_LAUNCH(k_instnorm_merge, dim3(dasr_cdiv(n, 256)), dim3(256), 0, stream, part, mean, var, HW, C, nchunks, n);
     DASR_RETURN_LAUNCH_STATUS();
 }

@@ -172,7 +172,9 @@ def instnorm_stats(x):
     B, H, W, C = x.shape
     mean = empty((B, C), x)
     var = empty((B, C), x)
-    _call("dasr_instnorm_stats", _p(x), _p(mean), _p(var), B, H * W, C)
+    nbytes = _lib.get().dasr_instnorm_stats_workspace(B, H * W, C)
+    ws = torch.empty((max(1, nbytes // 4),), dtype=torch.float32, device=x.device)
+    _call("dasr_instnorm_stats", _p(x), _p(mean), _p(var), _p(ws), nbytes, B, H * W, C)
     return mean, var
 
 

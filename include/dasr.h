@@ -106,9 +106,13 @@ int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw_hwio, float*
  * nn.InstanceNorm2d(affine=False) appears twice in a row on every DGB conv output
  * (sftmd_arch.py:811-820 then normalization.py:16-17,56).  Both collapse to one per-(b,c) scale:
  *   xhat = (x - mean) * rsqrt(var+eps) * rsqrt(var/(var+eps) + eps)      
- * This entry point computes mean and biased variance per (b,c) of an NHWC tensor.
+ * This entry point computes mean and biased variance per (b,c) of an NHWC tensor
+ * (chunked two-pass + Chan merge in a fixed order: no E[x^2]-mean^2 cancellation, bitwise reproducible).
+ * workspace: dasr_instnorm_stats_workspace() bytes.
  */
-int dasr_instnorm_stats(const float* x, float* mean, float* var, int B, int HW, int C, void* stream);
+size_t dasr_instnorm_stats_workspace(int B, int HW, int C);
+int dasr_instnorm_stats(const float* x, float* mean, float* var, void* workspace, size_t workspace_bytes, int B, int HW,
+                        int C, void* stream);
 
 /* ---- depth matrix -> per-sample dynamic kernels ------------------------------------------------
  * SEAN.A_i_j (1x1 conv over the K axis) and the collapse of mlp_gamma_s / mlp_beta_s over the

@@ -119,6 +119,7 @@ def check_conv_variants(device, seed=0):
         (1, 16, 3, 1, 1, False, 1, 1, False, 6, 5), (64, 64, 3, 1, 1, False, 0, 1, False, 9, 33),
         (32, 32, 3, 1, 1, False, 1, 1, True, 8, 34), (128, 128, 3, 1, 1, False, 0, 1, False, 5, 33),
         (64, 256, 3, 1, 1, False, 2, 2, False, 6, 9), (32, 128, 3, 1, 1, False, 2, 2, False, 10, 35),
+        (32, 3, 9, 1, 4, False, 0, 1, False, 11, 70), (32, 3, 9, 1, 4, False, 0, 1, False, 19, 60),
     ]
     worst = 0.0
     for (cin, cout, k, stride, pad, tr, act, ps, res, H, W) in cases:
@@ -156,7 +157,7 @@ def check_conv_variants(device, seed=0):
                  rel_max(bv.grad, b.grad)]
         if res:
             errs.append(rel_max(nchw(rv.grad), r.grad))
-        tol = 2e-5 if cin * k * k < 600 else 1e-4
+        tol = 2e-5 if cin * k * k < 600 else 2e-4
         assert max(errs) <= tol, ((cin, cout, k, stride, pad, tr, act, ps, res, H, W), errs)
         worst = max(worst, max(errs))
     return worst
