@@ -27,7 +27,8 @@ _is_device = None
 _CTYPES = {
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "void*": ctypes.c_void_p,
     "const void*": ctypes.c_void_p, "int": ctypes.c_int, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
-    "const char*": ctypes.c_char_p,
+    "const char*": ctypes.c_char_p, "const unsigned char*": ctypes.c_void_p, "unsigned char*": ctypes.c_void_p,
+    "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p,
 }
 
 
@@ -103,14 +104,14 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def ptr(t, allow_none=False):
-    """Raw device pointer of a contiguous fp32 tensor that lives where the library computes."""
+def ptr(t, allow_none=False, dtype=torch.float32):
+    """Raw device pointer of a contiguous tensor (fp32 unless told otherwise) that lives where the library computes."""
     if t is None:
         if allow_none:
             return None
         raise ValueError("dasr_amd: required tensor is None")
-    if t.dtype != torch.float32:
-        raise TypeError("dasr_amd: expected float32, got %s" % t.dtype)
+    if t.dtype != dtype:
+        raise TypeError("dasr_amd: expected %s, got %s" % (dtype, t.dtype))
     if not t.is_contiguous():
         raise ValueError("dasr_amd: tensor must be contiguous")
     if is_device_build() != t.is_cuda:

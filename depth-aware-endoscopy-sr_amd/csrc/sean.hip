@@ -76,7 +76,9 @@ __global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const float* __res
                                                   const float* __restrict__ D, const float* __restrict__ bias_g,
                                                   const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
                                                   const float* __restrict__ alpha_b, const float* __restrict__ residual,
-                                                  float* __restrict__ out, int relu, float eps) {
+                                                  float* __restrict__ out, int relu, float eps,
+                                                  const int* __restrict__ onehot_flag) {
+    if (onehot_flag && *onehot_flag == 0) return;   // one-hot masks: k_sean_fwd_onehot does the work
     DASR_DYN_SMEM(smem);
     float* sD = (float*)smem;
     float* sM = sD + sean_lds_D_floats(g.K);
@@ -113,21 +115,9 @@ __global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const float* __res
 }
 
 extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var, const float* gb2, const float* mask,
-                             const float* D, const float* bias_g, const float* bias_b, const float* alpha_g,
-                             const float* alpha_b, const float* residual, float* out, int relu, int B, int H, int W,
-                             int C, int K, float eps, void* stream) {
-    DASR_CHECK_PTR(t); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var); DASR_CHECK_PTR(gb2); DASR_CHECK_PTR(mask);
-    DASR_CHECK_PTR(D); DASR_CHECK_PTR(bias_g); DASR_CHECK_PTR(bias_b); DASR_CHECK_PTR(alpha_g); DASR_CHECK_PTR(alpha_b);
-    DASR_CHECK_PTR(out);
-    DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && C > 0 && K > 0);
-    if (K > SEAN_MAXK) return DASR_E_UNSUPPORTED;
-    SeanGeom g{B, H, W, C, K};
-    int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
-    size_t lds = sizeof(float) * (size_t)(2 * 9 * K * 64 + K * (SEAN_TH + 2) * (SEAN_TW + 2));
-    DASR_LAUNCH(k_sean_fwd, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2, mask, D,
-                bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps);
-    DASR_RETURN_LAUNCH_STATUS();
-}
+                             const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_g,
+                             const float* bias_b, const float* alpha_g, const float* alpha_b, const float* residual,
+                             float* out, int relu, int B, int H, int W, int C, int K, float eps, void* stream);
 
 // ---------------------------------------------------------------------------------------- backward
 // Pass A (per tile): g0 = dout*relu'(out); dgb2, dres; dxhat -> dt (temporarily); per-(b,c) sums
@@ -147,7 +137,8 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const float* __r
                                                     float* __restrict__ dbias_g, float* __restrict__ dbias_b,
                                                     float* __restrict__ dalpha_g, float* __restrict__ dalpha_b,
                                                     float* __restrict__ dres, float* __restrict__ S, int relu,
-                                                    float eps) {
+                                                    float eps, const int* __restrict__ onehot_flag) {
+    if (onehot_flag && *onehot_flag == 0) return;
     DASR_DYN_SMEM(smem);
     float* sD = (float*)smem;
     float* sM = sD + sean_lds_D_floats(g.K);
@@ -260,28 +251,391 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const float* __restrict__ t,
     }
 }
 
+
+// =====================================================================================================
+// One-hot fast path.
+//
+// The reference's masks are one-hot by construction (getDepthMask, LQGTker_Depth_dataset.py:204-225) and
+// stay binary through the 'nearest' resize (normalization.py:59).  dasr_mask_compress turns the K float
+// planes into one byte per pixel (region index, K = "no region") and raises a flag if any pixel is not
+// one-hot; the kernels below run when the flag is clear, the general kernels above when it is set — the
+// decision is taken ON THE DEVICE (both kernels are launched, one exits at its first instruction), so the
+// host never synchronises.
+//
+// With a region index the 3x3 dynamic convolution is a GATHER: gamma1[p][c] = bias + sum_tap D[tap][r(p+tap)][c],
+// 9 LDS row reads instead of 9*K multiply-adds.  Lane layout: 16 lanes x float4 = the 64 channels of one
+// pixel, 4 pixels per wave-instruction (1 KiB contiguous global accesses); every ds_read_b128 lane group
+// covers all 64 banks exactly once whatever rows the four pixels pick (rows are 64-dword multiples).
+// =====================================================================================================
+#define SF_TH 8
+#define SF_TW 32
+
+__global__ void __launch_bounds__(256) k_mask_compress(const float* __restrict__ mask, unsigned char* __restrict__ region,
+                                                       int* __restrict__ flag, int K, int HW, size_t n) {
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        size_t b = i / HW, p = i % HW;
+        int ones = 0, other = 0, idx = K;
+        for (int k = 0; k < K; ++k) {
+            float m = mask[(b * K + k) * HW + p];
+            if (m == 1.f) { ++ones; idx = k; }
+            else if (m != 0.f) ++other;
+        }
+        if (other != 0 || ones > 1) bad = 1;
+        region[i] = (unsigned char)idx;
+    }
+    if (bad) atomicAdd(flag, 1);
+}
+
+extern "C" int dasr_mask_compress(const float* mask, unsigned char* region, int* flag, int B, int K, int H, int W,
+                                  void* stream) {
+    DASR_CHECK_PTR(mask); DASR_CHECK_PTR(region); DASR_CHECK_PTR(flag);
+    DASR_CHECK_SHAPE(B > 0 && K > 0 && H > 0 && W > 0);
+    if (K > SEAN_MAXK) return DASR_E_UNSUPPORTED;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    size_t n = (size_t)B * H * W;
+    DASR_LAUNCH(k_mask_compress, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, mask, region, flag, K, H * W, n);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// stage D[b] (channel slice c0..c0+63) as [18][K+1][64] with a zero row K, and the region tile with halo
+__device__ __forceinline__ void sean_stage_onehot(const SeanGeom& g, const unsigned char* __restrict__ region,
+                                                  const float* __restrict__ D, float* sD, unsigned char* sR, int b,
+                                                  int c0, int y0, int x0, bool stage_D) {
+    const int K1 = g.K + 1;
+    if (stage_D)
+        for (int i = threadIdx.x; i < 18 * K1 * 64; i += blockDim.x) {
+            int cl = i & 63, r = i >> 6, k = r % K1, st = r / K1;
+            int c = c0 + cl;
+            sD[i] = (k < g.K && c < g.C) ? D[(((size_t)b * 18 + st) * g.K + k) * g.C + c] : 0.f;
+        }
+    for (int i = threadIdx.x; i < (SF_TH + 2) * (SF_TW + 2); i += blockDim.x) {
+        int gy = y0 + i / (SF_TW + 2) - 1, gx = x0 + i % (SF_TW + 2) - 1;
+        unsigned char v = (unsigned char)g.K;
+        if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = region[((size_t)b * g.H + gy) * g.W + gx];
+        sR[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float* __restrict__ t,
+                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                         const float* __restrict__ gb2,
+                                                         const unsigned char* __restrict__ region,
+                                                         const int* __restrict__ flag, const float* __restrict__ D,
+                                                         const float* __restrict__ bias_g,
+                                                         const float* __restrict__ bias_b,
+                                                         const float* __restrict__ alpha_g,
+                                                         const float* __restrict__ alpha_b,
+                                                         const float* __restrict__ residual, float* __restrict__ out,
+                                                         int relu, float eps) {
+    if (*flag != 0) return;   // masks are not one-hot: the general kernel does the work
+    DASR_DYN_SMEM(smem);
+    const int K1 = g.K + 1;
+    float* sD = (float*)smem;                                  // [18][K+1][64]
+    unsigned char* sR = (unsigned char*)(sD + 18 * K1 * 64);   // [(TH+2)*(TW+2)]
+    const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
+    const int x0 = (blockIdx.x % tiles_x) * SF_TW, y0 = (blockIdx.x / tiles_x) * SF_TH;
+    const int b = blockIdx.y, c0 = blockIdx.z * 64;
+    sean_stage_onehot(g, region, D, sD, sR, b, c0, y0, x0, true);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cq = lane & 15, ps = lane >> 4;
+    const int c = c0 + 4 * cq;
+    if (c >= g.C) return;
+    const float a_g = alpha_g[0], a_b = alpha_b[0];
+    const float4 mu = *(const float4*)(mean + (size_t)b * g.C + c);
+    const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
+    const float4 sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
+                                  dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
+    const float4 bg = *(const float4*)(bias_g + c), bb = *(const float4*)(bias_b + c);
+    // wave wv owns tile rows wv and wv+4; a wave-instruction covers 4 consecutive pixels of a row
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+        const int ly = wv + 4 * rr, y = y0 + ly;
+        if (y >= g.H) continue;
+#pragma unroll 2
+        for (int xs = 0; xs < SF_TW / 4; ++xs) {
+            const int lx = 4 * xs + ps, x = x0 + lx;
+            if (x >= g.W) continue;
+            const size_t p = ((size_t)b * g.H + y) * g.W + x;
+            const float4 tv = *(const float4*)(t + p * g.C + c);
+            const float4 g2 = *(const float4*)(gb2 + p * 2 * g.C + c);
+            const float4 b2 = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
+            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (residual) rv = *(const float4*)(residual + p * g.C + c);
+            float4 g1 = bg, b1 = bb;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int k = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
+                g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k) * 64 + 4 * cq));
+                b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k) * 64 + 4 * cq));
+            }
+            float4 o;
+            o.x = (tv.x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x) + a_b * b1.x + (1.f - a_b) * b2.x + rv.x;
+            o.y = (tv.y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y) + a_b * b1.y + (1.f - a_b) * b2.y + rv.y;
+            o.z = (tv.z - mu.z) * sc.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z) + a_b * b1.z + (1.f - a_b) * b2.z + rv.z;
+            o.w = (tv.w - mu.w) * sc.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w) + a_b * b1.w + (1.f - a_b) * b2.w + rv.w;
+            if (relu) {
+                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            *(float4*)(out + p * g.C + c) = o;
+        }
+    }
+}
+
+// ---- backward, pass A, one-hot -------------------------------------------------------------------------
+// 512 threads (8 waves, wave w = tile row w); a workgroup walks several tiles of ONE sample and keeps the
+// dynamic-kernel gradient in LDS.  Per lane the contribution G[p] = (a_g*dgamma, a_b*dbeta) goes to
+// dD[tap][r(p+tap)]; regions are spatially coherent, so each lane keeps a run-length accumulator per tap and
+// touches LDS (float atomics) only when the neighbour's region changes.  The workgroup writes its dD as a
+// slab; k_sean_dD_reduce sums the slabs in a fixed order.
+struct RunAcc { float4 g, b; };
+
+__device__ __forceinline__ void sean_flush(float* sdD, int K1, int tap, int k, int cq, const RunAcc& a) {
+    float* pg = sdD + ((0 * 9 + tap) * K1 + k) * 64 + 4 * cq;
+    float* pb = sdD + ((1 * 9 + tap) * K1 + k) * 64 + 4 * cq;
+    atomicAdd(pg + 0, a.g.x); atomicAdd(pg + 1, a.g.y); atomicAdd(pg + 2, a.g.z); atomicAdd(pg + 3, a.g.w);
+    atomicAdd(pb + 0, a.b.x); atomicAdd(pb + 1, a.b.y); atomicAdd(pb + 2, a.b.z); atomicAdd(pb + 3, a.b.w);
+}
+
+__global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
+    SeanGeom g, const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ t,
+    const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gb2,
+    const unsigned char* __restrict__ region, const int* __restrict__ flag, const float* __restrict__ D,
+    const float* __restrict__ bias_g, const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
+    const float* __restrict__ alpha_b, float* __restrict__ dt, float* __restrict__ dgb2, float* __restrict__ dD_slabs,
+    float* __restrict__ dbias_g, float* __restrict__ dbias_b, float* __restrict__ dalpha_g,
+    float* __restrict__ dalpha_b, float* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
+    if (*flag != 0) return;
+    DASR_DYN_SMEM(smem);
+    const int K1 = g.K + 1;
+    float* sD = (float*)smem;                          // [18][K+1][64]
+    float* sdD = sD + 18 * K1 * 64;                    // [18][K+1][64]
+    float* sred = sdD + 18 * K1 * 64;                  // [8 waves][18 floats x 16 cq] reduction scratch
+    unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);
+    const int b = blockIdx.y, c0 = blockIdx.z * 64;
+    const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cq = lane & 15, ps = lane >> 4;
+    const int c = c0 + 4 * cq;
+    const bool live = c < g.C;
+    for (int i = threadIdx.x; i < 18 * K1 * 64; i += blockDim.x) sdD[i] = 0.f;
+    const float a_g = alpha_g[0], a_b = alpha_b[0];
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, bg = mu, bb = mu;
+    if (live) {
+        mu = *(const float4*)(mean + (size_t)b * g.C + c);
+        const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
+        sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
+                         dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
+        bg = *(const float4*)(bias_g + c);
+        bb = *(const float4*)(bias_b + c);
+    }
+    float4 S1 = make_float4(0.f, 0.f, 0.f, 0.f), S2 = S1, dbg = S1, dbb = S1;
+    float dag = 0.f, dab = 0.f;
+    RunAcc run[9];
+    int kcur[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        run[tap].g = make_float4(0.f, 0.f, 0.f, 0.f);
+        run[tap].b = run[tap].g;
+        kcur[tap] = g.K;
+    }
+    bool first = true;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SF_TH;
+        __syncthreads();
+        sean_stage_onehot(g, region, D, sD, sR, b, c0, y0, x0, first);
+        first = false;
+        __syncthreads();
+        const int ly = wv, y = y0 + ly;
+        if (!live || y >= g.H) continue;
+#pragma unroll 1
+        for (int xs = 0; xs < SF_TW / 4; ++xs) {
+            const int lx = 4 * xs + ps, x = x0 + lx;
+            if (x >= g.W) continue;
+            const size_t p = ((size_t)b * g.H + y) * g.W + x;
+            float4 g0 = *(const float4*)(dout + p * g.C + c);
+            if (relu) {
+                const float4 ov = *(const float4*)(out + p * g.C + c);
+                g0.x = ov.x > 0.f ? g0.x : 0.f; g0.y = ov.y > 0.f ? g0.y : 0.f;
+                g0.z = ov.z > 0.f ? g0.z : 0.f; g0.w = ov.w > 0.f ? g0.w : 0.f;
+            }
+            if (dres) *(float4*)(dres + p * g.C + c) = g0;
+            const float4 tv = *(const float4*)(t + p * g.C + c);
+            const float4 g2 = *(const float4*)(gb2 + p * 2 * g.C + c);
+            const float4 b2 = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
+            float4 g1 = bg, b1 = bb;
+            int kk[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int k = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
+                kk[tap] = k;
+                g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k) * 64 + 4 * cq));
+                b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k) * 64 + 4 * cq));
+            }
+            const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
+            const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
+            const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
+            *(float4*)(dgb2 + p * 2 * g.C + c) =
+                make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y, (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w);
+            *(float4*)(dgb2 + p * 2 * g.C + g.C + c) =
+                make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y, (1.f - a_b) * g0.z, (1.f - a_b) * g0.w);
+            dag += dgam.x * (g1.x - g2.x) + dgam.y * (g1.y - g2.y) + dgam.z * (g1.z - g2.z) + dgam.w * (g1.w - g2.w);
+            dab += g0.x * (b1.x - b2.x) + g0.y * (b1.y - b2.y) + g0.z * (b1.z - b2.z) + g0.w * (b1.w - b2.w);
+            const float4 G1 = make_float4(a_g * dgam.x, a_g * dgam.y, a_g * dgam.z, a_g * dgam.w);
+            const float4 B1 = make_float4(a_b * g0.x, a_b * g0.y, a_b * g0.z, a_b * g0.w);
+            dbg = f4add(dbg, G1);
+            dbb = f4add(dbb, B1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (kk[tap] != kcur[tap]) {
+                    sean_flush(sdD, K1, tap, kcur[tap], cq, run[tap]);
+                    kcur[tap] = kk[tap];
+                    run[tap].g = G1;
+                    run[tap].b = B1;
+                } else {
+                    run[tap].g = f4add(run[tap].g, G1);
+                    run[tap].b = f4add(run[tap].b, B1);
+                }
+            }
+            float4 dxh;
+            dxh.x = g0.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x);
+            dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
+            dxh.z = g0.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z);
+            dxh.w = g0.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w);
+            *(float4*)(dt + p * g.C + c) = dxh;
+            S1 = f4add(S1, dxh);
+            S2.x = fmaf(dxh.x, xc.x, S2.x); S2.y = fmaf(dxh.y, xc.y, S2.y);
+            S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) sean_flush(sdD, K1, tap, kcur[tap], cq, run[tap]);
+    }
+    // reduce the per-channel sums over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
+    float vals[18] = {S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, dbg.x, dbg.y, dbg.z, dbg.w,
+                      dbb.x, dbb.y, dbb.z, dbb.w, dag, dab};
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+        vals[q] += __shfl_xor(vals[q], 16, 64);
+        vals[q] += __shfl_xor(vals[q], 32, 64);
+    }
+    if (ps == 0) {
+#pragma unroll
+        for (int q = 0; q < 18; ++q) sred[(wv * 18 + q) * 16 + cq] = vals[q];
+    }
+    __syncthreads();
+    if (wv == 0 && ps == 0) {
+        float r[18];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            r[q] = 0.f;
+            for (int w = 0; w < 8; ++w) r[q] += sred[(w * 18 + q) * 16 + cq];
+        }
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(&S[((size_t)b * g.C + c + j) * 2 + 0], r[j]);
+                atomicAdd(&S[((size_t)b * g.C + c + j) * 2 + 1], r[4 + j]);
+                atomicAdd(&dbias_g[c + j], r[8 + j]);
+                atomicAdd(&dbias_b[c + j], r[12 + j]);
+            }
+        }
+        float ra = r[16], rb = r[17];
+        for (int off = 8; off > 0; off >>= 1) {
+            ra += __shfl_xor(ra, off, 64);
+            rb += __shfl_xor(rb, off, 64);
+        }
+        if (cq == 0) {
+            atomicAdd(dalpha_g, ra);
+            atomicAdd(dalpha_b, rb);
+        }
+    }
+    // slab [b][blockIdx.x][18][K][C-slice]
+    float* slab = dD_slabs + ((size_t)b * gridDim.x + blockIdx.x) * 18 * g.K * g.C;
+    for (int i = threadIdx.x; i < 18 * g.K * 64; i += blockDim.x) {
+        int cl = i & 63, r = i >> 6, k = r % g.K, st = r / g.K;
+        if (c0 + cl < g.C) slab[((size_t)st * g.K + k) * g.C + c0 + cl] = sdD[(st * K1 + k) * 64 + cl];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sean_dD_reduce(const float* __restrict__ slabs, const int* __restrict__ flag,
+                                                        float* __restrict__ dD, int per_sample, int nslab, size_t n) {
+    if (*flag != 0) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        size_t b = i / per_sample, e = i % per_sample;
+        const float* p = slabs + b * (size_t)nslab * per_sample + e;
+        float acc = 0.f;
+        for (int s = 0; s < nslab; ++s) acc += p[(size_t)s * per_sample];
+        dD[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static int sean_bwd_blocks_per_sample(int B, int H, int W) {
+    int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
+    int n = 512 / B;
+    if (n < 1) n = 1;
+    if (n > ntiles) n = ntiles;
+    return n;
+}
+
+extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var, const float* gb2, const float* mask,
+                             const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_g,
+                             const float* bias_b, const float* alpha_g, const float* alpha_b, const float* residual,
+                             float* out, int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
+    DASR_CHECK_PTR(t); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var); DASR_CHECK_PTR(gb2); DASR_CHECK_PTR(mask);
+    DASR_CHECK_PTR(D); DASR_CHECK_PTR(bias_g); DASR_CHECK_PTR(bias_b); DASR_CHECK_PTR(alpha_g); DASR_CHECK_PTR(alpha_b);
+    DASR_CHECK_PTR(out);
+    if ((region == nullptr) != (onehot_flag == nullptr)) return DASR_E_NULL;
+    DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && C > 0 && K > 0);
+    if (K > SEAN_MAXK) return DASR_E_UNSUPPORTED;
+    SeanGeom g{B, H, W, C, K};
+    const bool fast = region != nullptr && (C % 4) == 0;
+    if (fast) {
+        int tiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
+        size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
+        DASR_LAUNCH(k_sean_fwd_onehot, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2,
+                    region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps);
+    }
+    int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
+    size_t lds = sizeof(float) * (size_t)(2 * 9 * K * 64 + K * (SEAN_TH + 2) * (SEAN_TW + 2));
+    DASR_LAUNCH(k_sean_fwd, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2, mask, D,
+                bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps, fast ? onehot_flag : (const int*)nullptr);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" size_t dasr_sean_bwd_workspace(int B, int H, int W, int C, int K) {
-    (void)H; (void)W; (void)K;
-    return sizeof(float) * 2 * (size_t)B * C;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
+    size_t S = 2 * (size_t)B * C;
+    size_t slabs = (size_t)B * sean_bwd_blocks_per_sample(B, H, W) * 18 * K * C;
+    return sizeof(float) * (S + slabs);
 }
 
 extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t, const float* mean, const float* var,
-                             const float* gb2, const float* mask, const float* D, const float* bias_g,
-                             const float* bias_b, const float* alpha_g, const float* alpha_b, float* dt, float* dgb2,
-                             float* dD, float* dbias_g, float* dbias_b, float* dalpha_g, float* dalpha_b, float* dres,
-                             void* workspace, size_t workspace_bytes, int relu, int B, int H, int W, int C, int K,
-                             float eps, void* stream) {
+                             const float* gb2, const float* mask, const unsigned char* region, const int* onehot_flag,
+                             const float* D, const float* bias_g, const float* bias_b, const float* alpha_g,
+                             const float* alpha_b, float* dt, float* dgb2, float* dD, float* dbias_g, float* dbias_b,
+                             float* dalpha_g, float* dalpha_b, float* dres, void* workspace, size_t workspace_bytes,
+                             int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
     DASR_CHECK_PTR(dout); DASR_CHECK_PTR(out); DASR_CHECK_PTR(t); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var);
     DASR_CHECK_PTR(gb2); DASR_CHECK_PTR(mask); DASR_CHECK_PTR(D); DASR_CHECK_PTR(bias_g); DASR_CHECK_PTR(bias_b);
     DASR_CHECK_PTR(alpha_g); DASR_CHECK_PTR(alpha_b); DASR_CHECK_PTR(dt); DASR_CHECK_PTR(dgb2); DASR_CHECK_PTR(dD);
     DASR_CHECK_PTR(dbias_g); DASR_CHECK_PTR(dbias_b); DASR_CHECK_PTR(dalpha_g); DASR_CHECK_PTR(dalpha_b);
     DASR_CHECK_PTR(workspace);
+    if ((region == nullptr) != (onehot_flag == nullptr)) return DASR_E_NULL;
     DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && C > 0 && K > 0);
     if (K > SEAN_MAXK) return DASR_E_UNSUPPORTED;
     if (workspace_bytes < dasr_sean_bwd_workspace(B, H, W, C, K)) return DASR_E_WORKSPACE;
     SeanGeom g{B, H, W, C, K};
     hipStream_t st = (hipStream_t)stream;
     float* S = (float*)workspace;
+    float* slabs = S + 2 * (size_t)B * C;
     hipError_t e;
     if ((e = hipMemsetAsync(S, 0, sizeof(float) * 2 * (size_t)B * C, st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(dD, 0, sizeof(float) * (size_t)B * 18 * K * C, st)) != hipSuccess) return (int)e;
@@ -289,10 +643,23 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
     if ((e = hipMemsetAsync(dbias_b, 0, sizeof(float) * (size_t)C, st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(dalpha_g, 0, sizeof(float), st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(dalpha_b, 0, sizeof(float), st)) != hipSuccess) return (int)e;
+    const bool fast = region != nullptr && (C % 4) == 0;
+    if (fast) {
+        int nblk = sean_bwd_blocks_per_sample(B, H, W);
+        int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
+        size_t lds = sizeof(float) * (size_t)(2 * 18 * (K + 1) * 64 + 8 * 18 * 16) + (SF_TH + 2) * (SF_TW + 2);
+        DASR_LAUNCH(k_sean_bwd_a_onehot, dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t, mean,
+                    var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
+                    dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
+        size_t n = (size_t)B * 18 * K * C;
+        DASR_LAUNCH(k_sean_dD_reduce, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, (const float*)slabs, onehot_flag, dD,
+                    18 * K * C, nblk, n);
+    }
     int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
     size_t lds = sizeof(float) * (size_t)(2 * (2 * 9 * K * 64) + K * (SEAN_TH + 2) * (SEAN_TW + 2) + 6 * 256);
     DASR_LAUNCH(k_sean_bwd_a, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, dout, out, t, mean, var, gb2,
-                mask, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, dD, dbias_g, dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps);
+                mask, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, dD, dbias_g, dbias_b, dalpha_g, dalpha_b, dres, S,
+                relu, eps, fast ? onehot_flag : (const int*)nullptr);
     size_t n = (size_t)B * H * W * C;
     DASR_LAUNCH(k_sean_bwd_b, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, t, mean, var, S, dt, H * W, C, n, eps);
     DASR_RETURN_LAUNCH_STATUS();

@@ -163,9 +163,10 @@ def dynk(tape, st, A_w, A_b, Wg, Wb):
 
 
 def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu):
+    """``mask`` is a MaskPack (float planes + region index + one-hot flag)."""
     mean, var = ops.instnorm_stats(t.data)
-    y = ops.sean_fwd(t.data, mean, var, gb2.data, mask, D.data, bias_g.data, bias_b.data, alpha_g.data, alpha_b.data,
-                     residual.data if residual is not None else None, relu)
+    y = ops.sean_fwd(t.data, mean, var, gb2.data, mask.planes, mask.region, mask.flag, D.data, bias_g.data, bias_b.data,
+                     alpha_g.data, alpha_b.data, residual.data if residual is not None else None, relu)
     out = Var(y, True)
 
     def bwd():
@@ -173,8 +174,8 @@ def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, 
             return
         want_dres = residual is not None and residual.requires_grad
         dt, dgb2, dD, dbg, dbb, dag, dab, dres = ops.sean_bwd(
-            out.grad, y, t.data, mean, var, gb2.data, mask, D.data, bias_g.data, bias_b.data, alpha_g.data,
-            alpha_b.data, relu, want_dres)
+            out.grad, y, t.data, mean, var, gb2.data, mask.planes, mask.region, mask.flag, D.data, bias_g.data,
+            bias_b.data, alpha_g.data, alpha_b.data, relu, want_dres)
         out.grad = None
         accum(t, dt)
         accum(gb2, dgb2)
@@ -188,6 +189,20 @@ def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, 
 
     tape.record(bwd)
     return out
+
+
+class MaskPack:
+    """The depth masks as the reference delivers them ([B,K,H,W] float planes) plus their compressed form
+    (one region byte per pixel and a device-side "not one-hot" flag, dasr_mask_compress)."""
+    __slots__ = ("planes", "region", "flag")
+
+    def __init__(self, planes):
+        self.planes = planes
+        self.region, self.flag = ops.mask_compress(planes)
+
+    @property
+    def shape(self):
+        return self.planes.shape
 
 
 # ---------------------------------------------------------------------------------------------
@@ -235,7 +250,7 @@ def depth_block(tape, P, name, x, depth_map, mask, st, consts):
     if depth_map.data.shape[1:3] != (H, W):      # F.interpolate(..., mode='nearest'), normalization.py:58-59
         d = ops.resize_nearest_nchw(depth_map.data.view(B, 1, *depth_map.data.shape[1:3]), H, W)
         depth_map = Var(d.view(B, H, W, 1))
-        mask = ops.resize_nearest_nchw(mask, H, W)
+        mask = MaskPack(ops.resize_nearest_nchw(mask.planes, H, W))
     t1 = conv(tape, x, pack(tape, P[name + ".conv1.0.weight"]), P[name + ".conv1.0.bias"])
     a = sean(tape, P, name + ".norm1", t1, depth_map, mask, st, None, True, consts)
     t2 = conv(tape, a, pack(tape, P[name + ".conv2.0.weight"]), P[name + ".conv2.0.bias"])
@@ -275,6 +290,7 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask):
                   transposed=True, act=L)
         e5 = conv(tape, e4, _wn(tape, P, "encoder.layer5"), P["encoder.layer5.bias"], stride=2)
         st = region_pool(tape, e5, depth_mask)
+    mask_pack = MaskPack(depth_mask) if st is not None else None
     # head (:920)
     h1 = conv(tape, e1, _wn(tape, P, "head.0"), P["head.0.bias"], act=L)
     fea_bef = conv(tape, h1, _wn(tape, P, "head.2"), P["head.2.bias"], act=L)
@@ -282,7 +298,7 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask):
     def run_block(i, x):
         name, kind, _ = plan[i]
         if kind == "depth":
-            return depth_block(tape, P, name, x, dm, depth_mask, st, consts)
+            return depth_block(tape, P, name, x, dm, mask_pack, st, consts)
         return classic_block(tape, P, name, x)
 
     fea = fea_bef

@@ -200,17 +200,34 @@ def dynk_bwd(dD, st, stp, A_w, Wg, Wb, dst_accum):
     return dWg, dWb, dA_w, dA_b
 
 
-def sean_fwd(t, mean, var, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu):
+def mask_compress(mask):
+    """Region index per pixel (uint8 [B,H,W]) + device flag (int32 [1], non-zero = masks are not one-hot)."""
+    B, K, H, W = mask.shape
+    region = torch.empty((B, H, W), dtype=torch.uint8, device=mask.device)
+    flag = torch.empty((1,), dtype=torch.int32, device=mask.device)
+    _call("dasr_mask_compress", _p(mask), _lib.ptr(region, dtype=torch.uint8), _lib.ptr(flag, dtype=torch.int32), B, K,
+          H, W)
+    return region, flag
+
+
+def _rf(region, flag):
+    if region is None:
+        return None, None
+    return _lib.ptr(region, dtype=torch.uint8), _lib.ptr(flag, dtype=torch.int32)
+
+
+def sean_fwd(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu):
     B, H, W, C = t.shape
     K = mask.shape[1]
     assert mask.shape == (B, K, H, W) and gb2.shape == (B, H, W, 2 * C) and D.shape == (B, 2, 9, K, C)
     out = torch.empty_like(t)
-    _call("dasr_sean_fwd", _p(t), _p(mean), _p(var), _p(gb2), _p(mask), _p(D), _p(bias_g), _p(bias_b), _p(alpha_g),
-          _p(alpha_b), _p(residual, True), _p(out), int(relu), B, H, W, C, K, IN_EPS)
+    rp, fp = _rf(region, flag)
+    _call("dasr_sean_fwd", _p(t), _p(mean), _p(var), _p(gb2), _p(mask), rp, fp, _p(D), _p(bias_g), _p(bias_b),
+          _p(alpha_g), _p(alpha_b), _p(residual, True), _p(out), int(relu), B, H, W, C, K, IN_EPS)
     return out
 
 
-def sean_bwd(dout, out, t, mean, var, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, relu, want_dres):
+def sean_bwd(dout, out, t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, relu, want_dres):
     B, H, W, C = t.shape
     K = mask.shape[1]
     lib = _lib.get()
@@ -222,7 +239,8 @@ def sean_bwd(dout, out, t, mean, var, gb2, mask, D, bias_g, bias_b, alpha_g, alp
     dbg, dbb = empty((C,), t), empty((C,), t)
     dag, dab = empty((1,), t), empty((1,), t)
     dres = torch.empty_like(t) if want_dres else None
-    _call("dasr_sean_bwd", _p(dout), _p(out), _p(t), _p(mean), _p(var), _p(gb2), _p(mask), _p(D), _p(bias_g),
+    rp, fp = _rf(region, flag)
+    _call("dasr_sean_bwd", _p(dout), _p(out), _p(t), _p(mean), _p(var), _p(gb2), _p(mask), rp, fp, _p(D), _p(bias_g),
           _p(bias_b), _p(alpha_g), _p(alpha_b), _p(dt), _p(dgb2), _p(dD), _p(dbg), _p(dbb), _p(dag), _p(dab),
           _p(dres, True), _p(ws), nbytes, int(relu), B, H, W, C, K, IN_EPS)
     return dt, dgb2, dD, dbg, dbb, dag, dab, dres

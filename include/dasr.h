@@ -140,9 +140,16 @@ int dasr_dynk_bwd(const float* dD, const float* st, const float* stp, const floa
  * t, out, residual: NHWC [B,H,W,C]; gb2: NHWC [B,H,W,2C] (gamma2 | beta2 = mlp_gamma_o | mlp_beta_o outputs);
  * mask: NCHW [B,K,H,W] as the reference delivers it (any float values); bias_gamma/bias_beta [C] are the
  * mlp_gamma_s / mlp_beta_s biases; alpha_gamma / alpha_beta are 1-element DEVICE tensors (trainable, normalization.py:30-35).
+ * region / onehot_flag: outputs of dasr_mask_compress for the same mask (both NULL: general kernel only).
  */
+/* One byte per pixel from the K mask planes: region[b,y,x] = k if mask[b,k,y,x] == 1 and every other plane is 0,
+ * K if all planes are 0; *onehot_flag is set to a non-zero value if ANY pixel is neither (soft / overlapping
+ * masks).  The SEAN entry points run a gather kernel when the flag is 0 and the general kernel otherwise; the
+ * choice is made on the device, the host never reads the flag. */
+int dasr_mask_compress(const float* mask, unsigned char* region, int* onehot_flag, int B, int K, int H, int W,
+                       void* stream);
 int dasr_sean_fwd(const float* t, const float* mean, const float* var, const float* gb2, const float* mask,
-                  const float* D, const float* bias_gamma, const float* bias_beta, const float* alpha_gamma,
+                  const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_gamma, const float* bias_beta, const float* alpha_gamma,
                   const float* alpha_beta, const float* residual, float* out, int relu, int B, int H, int W, int C,
                   int K, float eps, void* stream);
 /* Backward. Inputs as forward plus dout and the saved forward output `out` (for the ReLU mask).
@@ -150,7 +157,8 @@ int dasr_sean_fwd(const float* t, const float* mean, const float* var, const flo
  * dres (may be NULL; written = dout*relu') ; workspace: dasr_sean_bwd_workspace() bytes. */
 size_t dasr_sean_bwd_workspace(int B, int H, int W, int C, int K);
 int dasr_sean_bwd(const float* dout, const float* out, const float* t, const float* mean, const float* var,
-                  const float* gb2, const float* mask, const float* D, const float* bias_gamma, const float* bias_beta,
+                  const float* gb2, const float* mask, const unsigned char* region, const int* onehot_flag,
+                  const float* D, const float* bias_gamma, const float* bias_beta,
                   const float* alpha_gamma, const float* alpha_beta, float* dt, float* dgb2, float* dD,
                   float* dbias_gamma, float* dbias_beta, float* dalpha_gamma, float* dalpha_beta, float* dres,
                   void* workspace, size_t workspace_bytes, int relu, int B, int H, int W, int C, int K, float eps,

@@ -216,7 +216,7 @@ def check_sean_golden(device):
         tv = Var(nhwc(x).to(device), True)
         stv = Var(st.clone().to(device), True)
         dv = Var(dmap.reshape(B, H, W, 1).contiguous().to(device))
-        ov = graph.sean(tape, P, "n", tv, dv, dmask.contiguous().to(device), stv, None, False,
+        ov = graph.sean(tape, P, "n", tv, dv, graph.MaskPack(dmask.contiguous().to(device)), stv, None, False,
                         {"alpha_gamma": None, "alpha_beta": None})
         errs = [rel_max(nchw(ov.data), ref.detach())]
         ov.grad = nhwc(wgt).to(device)
@@ -260,7 +260,7 @@ def check_blocks(device):
     xv = Var(nhwc(x).to(device), True)
     stv = Var(st.clone().to(device), True)
     dv = Var(dmap.reshape(B, H, W, 1).contiguous().to(device))
-    out = graph.depth_block(tape, P, "b", xv, dv, dmask.contiguous().to(device), stv, {})
+    out = graph.depth_block(tape, P, "b", xv, dv, graph.MaskPack(dmask.contiguous().to(device)), stv, {})
     assert rel_max(nchw(out.data), g["out"]) <= 1e-5
     wgt = torch.cos(torch.arange(out.data.numel(), dtype=torch.float32) * 0.011).reshape(B, C, H, W)
     out.grad = nhwc(wgt).to(device)
