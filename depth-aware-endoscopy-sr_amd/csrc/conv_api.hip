@@ -32,6 +32,7 @@ extern "C" int dasr_conv2d_fwd(const float* x, const float* w, const float* bias
     if (conv_mfma_supported(g)) return conv_mfma_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
     if (conv9_mfma_supported(g) && act == DASR_ACT_NONE && ps_r == 1 && !residual)
         return conv9_mfma_fwd(g, x, w, bias, y, stream);
+    if (conv_gather_fwd_supported(g) && ps_r == 1 && !residual) return conv_gather_fwd(g, x, w, bias, y, act, stream);
     return conv_direct_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
 }
 
@@ -55,6 +56,7 @@ extern "C" int dasr_conv2d_dgrad(const float* dconv, const float* w, float* dx, 
     if (rc) return rc;
     if (conv_mfma_dgrad_supported(g)) return conv_mfma_dgrad(g, dconv, w, dx, accumulate, stream);
     if (conv9_mfma_supported(g)) return conv9_mfma_dgrad(g, dconv, w, dx, accumulate, stream);
+    if (conv_gather_dgrad_supported(g)) return conv_gather_dgrad(g, dconv, w, dx, accumulate, stream);
     return conv_direct_dgrad(g, dconv, w, dx, accumulate, stream);
 }
 
@@ -63,6 +65,7 @@ extern "C" size_t dasr_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int 
     ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
     if (check_geom(g) == DASR_OK && conv_mfma_wgrad_supported(g)) return conv_mfma_wgrad_workspace(g);
     if (check_geom(g) == DASR_OK && conv9_mfma_supported(g)) return conv9_mfma_wgrad_workspace(g);
+    if (check_geom(g) == DASR_OK && conv_gather_wgrad_supported(g)) return conv_gather_wgrad_workspace(g);
     return 0;
 }
 
@@ -81,6 +84,10 @@ extern "C" int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw, 
         if (!workspace) return DASR_E_NULL;
         if (workspace_bytes < conv9_mfma_wgrad_workspace(g)) return DASR_E_WORKSPACE;
         rc = conv9_mfma_wgrad(g, x, dconv, dw, workspace, stream);
+    } else if (conv_gather_wgrad_supported(g)) {
+        if (!workspace) return DASR_E_NULL;
+        if (workspace_bytes < conv_gather_wgrad_workspace(g)) return DASR_E_WORKSPACE;
+        rc = conv_gather_wgrad(g, x, dconv, dw, workspace, stream);
     } else {
         rc = conv_direct_wgrad(g, x, dconv, dw, stream);
     }

@@ -172,8 +172,8 @@ int conv_direct_dgrad(const ConvGeom& g, const float* dconv, const float* w, flo
 int conv_colsum(const float* m, float* out, size_t rows, int C, void* stream) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    unsigned nsplit = (unsigned)((rows + 1023) / 1024);
-    if (nsplit > 1024) nsplit = 1024;
+    unsigned nsplit = (unsigned)((rows + 255) / 256);
+    if (nsplit > 2048) nsplit = 2048;
     if (nsplit < 1) nsplit = 1;
     size_t rps = (rows + nsplit - 1) / nsplit;
     DASR_LAUNCH(k_colsum, dim3(dasr_cdiv(C, 64), nsplit), dim3(256), 0, stream, m, out, rows, C, rps);

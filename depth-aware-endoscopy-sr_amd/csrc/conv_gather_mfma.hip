@@ -1,0 +1,204 @@
+// conv_gather_mfma.hip — strided and transposed convolutions of the encoder (sftmd_arch.py:745-749:
+// 3x3 stride-2 Conv2d 32->64->128, ConvTranspose2d 128->L, Conv2d L->L stride 2) on the fp32 matrix cores.
+//
+// These layers are 0.8 % of the FLOPs and work on 64x80 .. 32x40 images, so they do not get an LDS-tiled
+// kernel: operands are gathered straight from global memory (L2-resident: the whole encoder state of a
+// frame is a few MB), one 32-pixel M-tile per wave, no barriers.
+//
+//   GATHER 0 ("conv"):       src(m, tap) = (oy*stride - pad + kh, ox*stride - pad + kw)
+//   GATHER 1 ("transposed"): src(m, tap) = ((oy + pad - kh)/stride, (ox + pad - kw)/stride) when divisible
+// forward of Conv2d = GATHER 0, forward of ConvTranspose2d = GATHER 1; dgrad swaps them (and reads the
+// HWIO kernel transposed, WT = 1).  wgrad: M = ci, N = co, K = output pixels, one (tap, ci-tile, co-pair)
+// per wave, pixel range split over blockIdx.y into slabs summed by k_wgrad_reduce-style reduction.
+#include "dasr_common.h"
+#include "conv_kernels.h"
+
+struct GatherArgs {
+    const float* in;     // [B,Hi,Wi,Kd]   (gathered operand)
+    const float* w;      // HWIO of the forward convolution
+    const float* bias;
+    float* out;          // [B,Ho,Wo,Nd]
+    int B, Hi, Wi, Kd, Ho, Wo, Nd;
+    int KH, KW, stride, pad, gather, wt, act, accumulate;
+};
+
+__device__ __forceinline__ bool gather_src(const GatherArgs& a, int oy, int ox, int kh, int kw, int& iy, int& ix) {
+    if (a.gather == 0) {
+        iy = oy * a.stride - a.pad + kh;
+        ix = ox * a.stride - a.pad + kw;
+    } else {
+        int ty = oy + a.pad - kh, tx = ox + a.pad - kw;
+        if (ty < 0 || tx < 0 || (ty % a.stride) != 0 || (tx % a.stride) != 0) return false;
+        iy = ty / a.stride;
+        ix = tx / a.stride;
+    }
+    return iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) k_conv_gather_mfma(GatherArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const size_t M = (size_t)a.B * a.Ho * a.Wo;
+    const size_t m = ((size_t)blockIdx.x * 4 + wv) * 32 + li;      // this lane's output pixel (A row)
+    const int n0 = blockIdx.y * 32 * NT;
+    const bool mvalid = m < M;
+    int ox = 0, oy = 0, b = 0;
+    if (mvalid) {
+        ox = (int)(m % a.Wo);
+        oy = (int)((m / a.Wo) % a.Ho);
+        b = (int)(m / ((size_t)a.Wo * a.Ho));
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (int kh = 0; kh < a.KH; ++kh)
+        for (int kw = 0; kw < a.KW; ++kw) {
+            int iy, ix;
+            const bool ok = mvalid && gather_src(a, oy, ox, kh, kw, iy, ix);
+            const float* src = ok ? a.in + (((size_t)b * a.Hi + iy) * a.Wi + ix) * a.Kd : a.in;
+            const int tap = kh * a.KW + kw;
+            for (int c0 = 0; c0 < a.Kd; c0 += 8) {
+                float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) A = *(const float4*)(src + c0 + 4 * lh);
+                float4 Bf[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int nn = n0 + 32 * n + li;
+                    if (a.wt == 0) {
+                        const float* wp = a.w + ((size_t)tap * a.Kd + c0 + 4 * lh) * a.Nd + nn;
+                        Bf[n] = make_float4(wp[0], wp[a.Nd], wp[2 * (size_t)a.Nd], wp[3 * (size_t)a.Nd]);
+                    } else {
+                        Bf[n] = *(const float4*)(a.w + ((size_t)tap * a.Nd + nn) * a.Kd + c0 + 4 * lh);
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, Bf[n].x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, Bf[n].y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, Bf[n].z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, Bf[n].w, acc[n], 0, 0, 0);
+                }
+            }
+        }
+    // D: column = lane&31 = output channel, rows = pixels of this wave's M-tile
+    const size_t mbase = ((size_t)blockIdx.x * 4 + wv) * 32;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int nn = n0 + 32 * n + li;
+        const float bv = a.bias ? a.bias[nn] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t mm = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (mm >= M) continue;
+            float v = dasr_act(acc[n][r] + bv, a.act);
+            const size_t o = mm * a.Nd + nn;
+            if (a.accumulate) v += a.out[o];
+            a.out[o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+struct GatherWgradArgs {
+    const float* x;      // forward input  [B,H,W,Cin]
+    const float* dy;     // dconv          [B,Ho,Wo,Cout]
+    float* slabs;        // [P][taps][Cin][Cout]
+    int B, H, W, Cin, Ho, Wo, Cout;
+    int KH, KW, stride, pad, transposed;
+    int P;
+};
+
+__global__ void __launch_bounds__(256) k_conv_gather_wgrad_mfma(GatherWgradArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int ci_tiles = a.Cin / 32, co_pairs = a.Cout / 64;
+    const int item = blockIdx.x * 4 + wv;
+    const int nitems = a.KH * a.KW * ci_tiles * co_pairs;
+    if (item >= nitems) return;     // whole wave exits together (item is wave-uniform)
+    const int cp = item % co_pairs, ct = (item / co_pairs) % ci_tiles, tap = item / (co_pairs * ci_tiles);
+    const int kh = tap / a.KW, kw = tap % a.KW;
+    const size_t M = (size_t)a.B * a.Ho * a.Wo;
+    const size_t per = (M + a.P - 1) / a.P;
+    const size_t m0 = (size_t)blockIdx.y * per;
+    const size_t m1 = m0 + per < M ? m0 + per : M;
+    GatherArgs ga{};
+    ga.Hi = a.H; ga.Wi = a.W; ga.stride = a.stride; ga.pad = a.pad; ga.gather = a.transposed;
+    f32x16 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (size_t mb = m0; mb < m1; mb += 2) {
+        const size_t m = mb + lh;
+        float av = 0.f, b0 = 0.f, b1 = 0.f;
+        if (m < m1) {
+            const int ox = (int)(m % a.Wo), oy = (int)((m / a.Wo) % a.Ho), b = (int)(m / ((size_t)a.Wo * a.Ho));
+            int iy, ix;
+            if (gather_src(ga, oy, ox, kh, kw, iy, ix))
+                av = a.x[(((size_t)b * a.H + iy) * a.W + ix) * a.Cin + 32 * ct + li];
+            const float* dp = a.dy + m * a.Cout + 64 * cp + li;
+            b0 = dp[0];
+            b1 = dp[32];
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+    }
+    float* slab = a.slabs + (size_t)blockIdx.y * a.KH * a.KW * a.Cin * a.Cout;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[((size_t)tap * a.Cin + ci) * a.Cout + 64 * cp + 32 * n + li] = acc[n][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+bool conv_gather_fwd_supported(const ConvGeom& g) { return (g.Cin % 8) == 0 && (g.Cout % 32) == 0; }
+bool conv_gather_dgrad_supported(const ConvGeom& g) { return (g.Cout % 8) == 0 && (g.Cin % 32) == 0; }
+bool conv_gather_wgrad_supported(const ConvGeom& g) { return (g.Cin % 32) == 0 && (g.Cout % 64) == 0; }
+
+static int launch_gather(GatherArgs& a, void* stream) {
+    size_t M = (size_t)a.B * a.Ho * a.Wo;
+    unsigned gx = dasr_cdiv(M, 128);
+    if ((a.Nd % 64) == 0) {
+        DASR_LAUNCH((k_conv_gather_mfma<2>), dim3(gx, a.Nd / 64), dim3(256), 0, stream, a);
+    } else {
+        DASR_LAUNCH((k_conv_gather_mfma<1>), dim3(gx, a.Nd / 32), dim3(256), 0, stream, a);
+    }
+    DASR_RETURN_LAUNCH_STATUS();
+}
+int conv_gather_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                    void* stream) {
+    GatherArgs a{x, w, bias, y, g.B, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout, g.KH, g.KW, g.stride, g.pad,
+                 g.transposed ? 1 : 0, 0, act, 0};
+    return launch_gather(a, stream);
+}
+int conv_gather_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream) {
+    GatherArgs a{dconv, w, nullptr, dx, g.B, g.Ho, g.Wo, g.Cout, g.H, g.W, g.Cin, g.KH, g.KW, g.stride, g.pad,
+                 g.transposed ? 0 : 1, 1, DASR_ACT_NONE, accumulate};
+    return launch_gather(a, stream);
+}
+static int gather_wgrad_P(const ConvGeom& g) {
+    int items = g.KH * g.KW * (g.Cin / 32) * (g.Cout / 64);
+    int blocks = (items + 3) / 4;
+    int P = 1024 / blocks;
+    if (P < 1) P = 1;
+    size_t M = (size_t)g.B * g.Ho * g.Wo;
+    size_t maxP = (M + 255) / 256;
+    if ((size_t)P > maxP) P = (int)maxP;
+    if (P < 1) P = 1;
+    return P;
+}
+size_t conv_gather_wgrad_workspace(const ConvGeom& g) {
+    return sizeof(float) * (size_t)gather_wgrad_P(g) * g.KH * g.KW * g.Cin * g.Cout;
+}
+int conv_gather_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream) {
+    int P = gather_wgrad_P(g);
+    GatherWgradArgs a{x, dconv, (float*)workspace, g.B, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout,
+                      g.KH, g.KW, g.stride, g.pad, g.transposed ? 1 : 0, P};
+    int items = g.KH * g.KW * (g.Cin / 32) * (g.Cout / 64);
+    DASR_LAUNCH(k_conv_gather_wgrad_mfma, dim3((items + 3) / 4, P), dim3(256), 0, stream, a);
+    return wgrad_reduce_launch((const float*)workspace, dw, (size_t)g.KH * g.KW * g.Cin * g.Cout, P, stream);
+}

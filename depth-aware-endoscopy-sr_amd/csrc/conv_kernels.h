@@ -41,3 +41,14 @@ int conv9_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const floa
 int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
 size_t conv9_mfma_wgrad_workspace(const ConvGeom& g);
 int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream);
+
+// conv_gather_mfma.hip (any stride / transposed; Cin % 8 == 0, Cout % 32 == 0: the encoder layers)
+bool conv_gather_fwd_supported(const ConvGeom& g);
+bool conv_gather_dgrad_supported(const ConvGeom& g);
+bool conv_gather_wgrad_supported(const ConvGeom& g);
+int conv_gather_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                    void* stream);
+int conv_gather_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
+size_t conv_gather_wgrad_workspace(const ConvGeom& g);
+int conv_gather_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream);
+int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* stream);

@@ -262,13 +262,48 @@ __global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, size_t n,
-                                                      int P) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float acc = 0.f;
-        for (int p = 0; p < P; ++p) acc += slabs[(size_t)p * n + i];
-        dw[i] = acc;
+// dw = sum of P slabs.  float4 per thread, the slab range split over blockIdx.y (partial sums meet in dw through
+// float atomics when gridDim.y > 1; dw is zeroed first).
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, size_t n4,
+                                                      int P, int per_y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int p0 = blockIdx.y * per_y;
+    const int p1 = p0 + per_y < P ? p0 + per_y : P;
+    const float4* src = (const float4*)slabs + i;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int p = p0;
+    for (; p + 1 < p1; p += 2) {
+        float4 v0 = src[(size_t)p * n4], v1 = src[(size_t)(p + 1) * n4];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
     }
+    if (p < p1) {
+        float4 v0 = src[(size_t)p * n4];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    a0.x += a1.x; a0.y += a1.y; a0.z += a1.z; a0.w += a1.w;
+    float* d = dw + 4 * i;
+    if (gridDim.y == 1) {
+        *(float4*)d = a0;
+    } else {
+        atomicAdd(d + 0, a0.x); atomicAdd(d + 1, a0.y); atomicAdd(d + 2, a0.z); atomicAdd(d + 3, a0.w);
+    }
+}
+
+int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* stream) {
+    // n is a multiple of 4 for every supported shape (Cout % 32 == 0)
+    size_t n4 = n / 4;
+    unsigned gx = dasr_cdiv(n4, 256);
+    int ysplit = 1;
+    while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
+    int per_y = (P + ysplit - 1) / ysplit;
+    if (ysplit > 1) {
+        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * n, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    DASR_LAUNCH(k_wgrad_reduce, dim3(gx, ysplit), dim3(256), 0, stream, slabs, dw, n4, P, per_y);
+    DASR_RETURN_LAUNCH_STATUS();
 }
 
 bool conv_mfma_wgrad_supported(const ConvGeom& g) {
@@ -280,7 +315,7 @@ static void wgrad_plan(const ConvGeom& g, int& MT, int& NTW, int& groups, int& n
     NTW = (g.Cout % 64) == 0 ? 2 : 1;
     groups = (g.Cin / (32 * MT)) * (g.Cout / (32 * NTW));
     ntiles = g.B * ((g.H + WG_TH - 1) / WG_TH) * ((g.W + WG_TW - 1) / WG_TW);
-    P = 1024 / groups;
+    P = 512 / groups;
     if (P < 1) P = 1;
     if (P > ntiles) P = ntiles;
 }
@@ -304,7 +339,5 @@ int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float
     } else {
         DASR_LAUNCH((k_conv3x3_wgrad_mfma<1, 1>), grid, dim3(256), lds, stream, a);
     }
-    size_t n = (size_t)9 * g.Cin * g.Cout;
-    DASR_LAUNCH(k_wgrad_reduce, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, (const float*)workspace, dw, n, P);
-    DASR_RETURN_LAUNCH_STATUS();
+    return wgrad_reduce_launch((const float*)workspace, dw, (size_t)9 * g.Cin * g.Cout, P, stream);
 }

@@ -53,40 +53,41 @@ __global__ void k_dynk_dW(const float* __restrict__ dD, const float* __restrict_
         (s ? dWb : dWg)[((size_t)c * L + l) * 9 + tap] = acc;
     }
 }
-// dstp[b,k,l] = sum_{s,tap,c} dD[b,s,tap,k,c] * W_s[c,l,tap]
+// dstp[b,k,l] = sum_{s,tap,c} dD[b,s,tap,k,c] * W_s[c,l,tap]; blockIdx.y = (s,tap) slice, partial sums are
+// added with float atomics into the zeroed dstp (18 adds per element)
 __global__ void k_dynk_dstp(const float* __restrict__ dD, const float* __restrict__ Wg, const float* __restrict__ Wb,
                             float* __restrict__ dstp, int K, int L, int C, size_t n) {
+    const int st = blockIdx.y, s = st / 9, tap = st % 9;
+    const float* Wp = s ? Wb : Wg;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         int l = (int)(i % L), k = (int)((i / L) % K);
         size_t b = i / ((size_t)L * K);
+        const float* dp = dD + ((b * 18 + st) * K + k) * C;
         float acc = 0.f;
-        for (int s = 0; s < 2; ++s) {
-            const float* Wp = s ? Wb : Wg;
-            for (int tap = 0; tap < 9; ++tap) {
-                const float* dp = dD + (((b * 2 + s) * 9 + tap) * K + k) * C;
-                for (int c = 0; c < C; ++c) acc = fmaf(dp[c], Wp[((size_t)c * L + l) * 9 + tap], acc);
-            }
-        }
-        dstp[i] = acc;
+        for (int c = 0; c < C; ++c) acc = fmaf(dp[c], Wp[((size_t)c * L + l) * 9 + tap], acc);
+        atomicAdd(&dstp[i], acc);
     }
 }
-// dA_w[k,j] = sum_{b,l} dstp[b,k,l]*st[b,j,l]; dA_b[k] = sum_{b,l} dstp[b,k,l]   (threads K*K .. K*K+K-1 do the bias)
-__global__ void k_dynk_dA(const float* __restrict__ dstp, const float* __restrict__ st, float* __restrict__ dA_w,
-                          float* __restrict__ dA_b, int B, int K, int L) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < K * K) {
-        int k = i / K, j = i % K;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            for (int l = 0; l < L; ++l)
-                acc = fmaf(dstp[((size_t)b * K + k) * L + l], st[((size_t)b * K + j) * L + l], acc);
-        dA_w[i] = acc;
-    } else if (i < K * K + K) {
-        int k = i - K * K;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            for (int l = 0; l < L; ++l) acc += dstp[((size_t)b * K + k) * L + l];
-        dA_b[k] = acc;
+// dA_w[k,j] = sum_{b,l} dstp[b,k,l]*st[b,j,l]; dA_b[k] = sum_{b,l} dstp[b,k,l]; one workgroup per output
+__global__ void __launch_bounds__(256) k_dynk_dA(const float* __restrict__ dstp, const float* __restrict__ st,
+                                                 float* __restrict__ dA_w, float* __restrict__ dA_b, int B, int K,
+                                                 int L) {
+    __shared__ float red[4];
+    const int e = blockIdx.x;
+    const bool is_bias = e >= K * K;
+    const int k = is_bias ? e - K * K : e / K, j = is_bias ? 0 : e % K;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B * L; i += 256) {
+        int b = i / L, l = i % L;
+        float d = dstp[((size_t)b * K + k) * L + l];
+        acc += is_bias ? d : d * st[((size_t)b * K + j) * L + l];
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = red[0] + red[1] + red[2] + red[3];
+        if (is_bias) dA_b[k] = r; else dA_w[e] = r;
     }
 }
 // dst[b,j,l] += sum_k A_w[k,j] * dstp[b,k,l]
@@ -109,8 +110,10 @@ extern "C" int dasr_dynk_bwd(const float* dD, const float* st, const float* stp,
     DASR_CHECK_SHAPE(B > 0 && K > 0 && L > 0 && C > 0);
     size_t nW = (size_t)2 * C * L * 9, nS = (size_t)B * K * L;
     DASR_LAUNCH(k_dynk_dW, dim3(dasr_ew_grid(nW)), dim3(256), 0, stream, dD, stp, dWg, dWb, B, K, L, C, nW);
-    DASR_LAUNCH(k_dynk_dstp, dim3(dasr_ew_grid(nS)), dim3(256), 0, stream, dD, Wg, Wb, dstp, K, L, C, nS);
-    DASR_LAUNCH(k_dynk_dA, dim3(dasr_cdiv(K * K + K, 64)), dim3(64), 0, stream, dstp, st, dA_w, dA_b, B, K, L);
+    hipError_t e = hipMemsetAsync(dstp, 0, sizeof(float) * nS, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    DASR_LAUNCH(k_dynk_dstp, dim3(dasr_ew_grid(nS), 18), dim3(256), 0, stream, dD, Wg, Wb, dstp, K, L, C, nS);
+    DASR_LAUNCH(k_dynk_dA, dim3(K * K + K), dim3(256), 0, stream, dstp, st, dA_w, dA_b, B, K, L);
     DASR_LAUNCH(k_dynk_dst, dim3(dasr_ew_grid(nS)), dim3(256), 0, stream, dstp, A_w, dst, K, L, nS);
     DASR_RETURN_LAUNCH_STATUS();
 }

@@ -389,17 +389,16 @@ __global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float
 
 // ---- backward, pass A, one-hot -------------------------------------------------------------------------
 // 512 threads (8 waves, wave w = tile row w); a workgroup walks several tiles of ONE sample and keeps the
-// dynamic-kernel gradient in LDS.  Per lane the contribution G[p] = (a_g*dgamma, a_b*dbeta) goes to
-// dD[tap][r(p+tap)]; regions are spatially coherent, so each lane keeps a run-length accumulator per tap and
-// touches LDS (float atomics) only when the neighbour's region changes.  The workgroup writes its dD as a
-// slab; k_sean_dD_reduce sums the slabs in a fixed order.
-struct RunAcc { float4 g, b; };
-
-__device__ __forceinline__ void sean_flush(float* sdD, int K1, int tap, int k, int cq, const RunAcc& a) {
+// dynamic-kernel gradient in LDS: the contribution G[p] = (a_g*dgamma, a_b*dbeta) is added to
+// dD[tap][r(p+tap)] with LDS float atomics (ds_add_f32), two copies of the accumulator (even / odd pixel
+// sub-lane) halving same-address collisions.  The workgroup writes its dD as a slab; k_sean_dD_reduce sums
+// the slabs in a fixed order.
+__device__ __forceinline__ void sean_scatter(float* sdD, int K1, int tap, int k, int cq, const float4& G1,
+                                             const float4& B1) {
     float* pg = sdD + ((0 * 9 + tap) * K1 + k) * 64 + 4 * cq;
     float* pb = sdD + ((1 * 9 + tap) * K1 + k) * 64 + 4 * cq;
-    atomicAdd(pg + 0, a.g.x); atomicAdd(pg + 1, a.g.y); atomicAdd(pg + 2, a.g.z); atomicAdd(pg + 3, a.g.w);
-    atomicAdd(pb + 0, a.b.x); atomicAdd(pb + 1, a.b.y); atomicAdd(pb + 2, a.b.z); atomicAdd(pb + 3, a.b.w);
+    atomicAdd(pg + 0, G1.x); atomicAdd(pg + 1, G1.y); atomicAdd(pg + 2, G1.z); atomicAdd(pg + 3, G1.w);
+    atomicAdd(pb + 0, B1.x); atomicAdd(pb + 1, B1.y); atomicAdd(pb + 2, B1.z); atomicAdd(pb + 3, B1.w);
 }
 
 __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
@@ -414,8 +413,8 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     DASR_DYN_SMEM(smem);
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                          // [18][K+1][64]
-    float* sdD = sD + 18 * K1 * 64;                    // [18][K+1][64]
-    float* sred = sdD + 18 * K1 * 64;                  // [8 waves][18 floats x 16 cq] reduction scratch
+    float* sdD = sD + 18 * K1 * 64;                    // [2 copies][18][K+1][64]
+    float* sred = sdD + 2 * 18 * K1 * 64;              // [8 waves][18 floats x 16 cq] reduction scratch
     unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);
     const int b = blockIdx.y, c0 = blockIdx.z * 64;
     const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
@@ -423,7 +422,8 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     const int cq = lane & 15, ps = lane >> 4;
     const int c = c0 + 4 * cq;
     const bool live = c < g.C;
-    for (int i = threadIdx.x; i < 18 * K1 * 64; i += blockDim.x) sdD[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * 18 * K1 * 64; i += blockDim.x) sdD[i] = 0.f;
+    float* sdD_mine = sdD + (ps & 1) * 18 * K1 * 64;
     const float a_g = alpha_g[0], a_b = alpha_b[0];
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, bg = mu, bb = mu;
     if (live) {
@@ -436,14 +436,6 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     }
     float4 S1 = make_float4(0.f, 0.f, 0.f, 0.f), S2 = S1, dbg = S1, dbb = S1;
     float dag = 0.f, dab = 0.f;
-    RunAcc run[9];
-    int kcur[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        run[tap].g = make_float4(0.f, 0.f, 0.f, 0.f);
-        run[tap].b = run[tap].g;
-        kcur[tap] = g.K;
-    }
     bool first = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SF_TH;
@@ -491,17 +483,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             dbg = f4add(dbg, G1);
             dbb = f4add(dbb, B1);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                if (kk[tap] != kcur[tap]) {
-                    sean_flush(sdD, K1, tap, kcur[tap], cq, run[tap]);
-                    kcur[tap] = kk[tap];
-                    run[tap].g = G1;
-                    run[tap].b = B1;
-                } else {
-                    run[tap].g = f4add(run[tap].g, G1);
-                    run[tap].b = f4add(run[tap].b, B1);
-                }
-            }
+            for (int tap = 0; tap < 9; ++tap) sean_scatter(sdD_mine, K1, tap, kk[tap], cq, G1, B1);
             float4 dxh;
             dxh.x = g0.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x);
             dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
@@ -512,10 +494,6 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             S2.x = fmaf(dxh.x, xc.x, S2.x); S2.y = fmaf(dxh.y, xc.y, S2.y);
             S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
         }
-    }
-    if (live) {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) sean_flush(sdD, K1, tap, kcur[tap], cq, run[tap]);
     }
     // reduce the per-channel sums over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
     float vals[18] = {S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, dbg.x, dbg.y, dbg.z, dbg.w,
@@ -560,7 +538,9 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     float* slab = dD_slabs + ((size_t)b * gridDim.x + blockIdx.x) * 18 * g.K * g.C;
     for (int i = threadIdx.x; i < 18 * g.K * 64; i += blockDim.x) {
         int cl = i & 63, r = i >> 6, k = r % g.K, st = r / g.K;
-        if (c0 + cl < g.C) slab[((size_t)st * g.K + k) * g.C + c0 + cl] = sdD[(st * K1 + k) * 64 + cl];
+        if (c0 + cl < g.C)
+            slab[((size_t)st * g.K + k) * g.C + c0 + cl] =
+                sdD[(st * K1 + k) * 64 + cl] + sdD[18 * K1 * 64 + (st * K1 + k) * 64 + cl];
     }
 }
 
@@ -579,7 +559,7 @@ __global__ void __launch_bounds__(256) k_sean_dD_reduce(const float* __restrict_
 // ------------------------------------------------------------------------------------------ host side
 static int sean_bwd_blocks_per_sample(int B, int H, int W) {
     int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
-    int n = 512 / B;
+    int n = 256 / B;
     if (n < 1) n = 1;
     if (n > ntiles) n = ntiles;
     return n;
@@ -647,7 +627,7 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
     if (fast) {
         int nblk = sean_bwd_blocks_per_sample(B, H, W);
         int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
-        size_t lds = sizeof(float) * (size_t)(2 * 18 * (K + 1) * 64 + 8 * 18 * 16) + (SF_TH + 2) * (SF_TW + 2);
+        size_t lds = sizeof(float) * (size_t)(3 * 18 * (K + 1) * 64 + 8 * 18 * 16) + (SF_TH + 2) * (SF_TW + 2);
         DASR_LAUNCH(k_sean_bwd_a_onehot, dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t, mean,
                     var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
                     dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);

@@ -120,6 +120,9 @@ def check_conv_variants(device, seed=0):
         (32, 32, 3, 1, 1, False, 1, 1, True, 8, 34), (128, 128, 3, 1, 1, False, 0, 1, False, 5, 33),
         (64, 256, 3, 1, 1, False, 2, 2, False, 6, 9), (32, 128, 3, 1, 1, False, 2, 2, False, 10, 35),
         (32, 3, 9, 1, 4, False, 0, 1, False, 11, 70), (32, 3, 9, 1, 4, False, 0, 1, False, 19, 60),
+        (32, 64, 3, 2, 1, False, 2, 1, False, 16, 20), (64, 128, 3, 2, 1, False, 2, 1, False, 9, 11),
+        (128, 64, 3, 2, 1, True, 2, 1, False, 5, 6), (64, 64, 3, 2, 1, False, 0, 1, False, 11, 13),
+        (8, 32, 3, 1, 1, False, 1, 1, False, 7, 9),
     ]
     worst = 0.0
     for (cin, cout, k, stride, pad, tr, act, ps, res, H, W) in cases:
