@@ -300,23 +300,63 @@ extern "C" int dasr_mask_compress(const float* mask, unsigned char* region, int*
 }
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4neg(float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
 
-// stage D[b] (channel slice c0..c0+63) as [18][K+1][64] with a zero row K, and the region tile with halo
+// LDS carve of the one-hot kernels (floats): sD [18][K+1][64] | sDsum [2][K+1][64] (sum over the 9 taps)
+// Row K of every table is zero ("no region": outside the image or a pixel no mask claims).
+// Most pixels sit inside a region: all 9 neighbours carry the same index k0 and the dynamic conv collapses
+// to ONE row read, gamma1 = bias + Dsum[0][k0].  Only waves that touch a region boundary gather 9 rows.
 __device__ __forceinline__ void sean_stage_onehot(const SeanGeom& g, const unsigned char* __restrict__ region,
-                                                  const float* __restrict__ D, float* sD, unsigned char* sR, int b,
-                                                  int c0, int y0, int x0, bool stage_D) {
+                                                  const float* __restrict__ D, float* sD, float* sDsum,
+                                                  unsigned char* sR, int b, int c0, int y0, int x0, bool stage_D) {
     const int K1 = g.K + 1;
-    if (stage_D)
-        for (int i = threadIdx.x; i < 18 * K1 * 64; i += blockDim.x) {
-            int cl = i & 63, r = i >> 6, k = r % K1, st = r / K1;
+    if (stage_D) {
+        for (int i = threadIdx.x; i < 2 * K1 * 64; i += blockDim.x) {
+            int cl = i & 63, k = (i >> 6) % K1, s = i / (64 * K1);
             int c = c0 + cl;
-            sD[i] = (k < g.K && c < g.C) ? D[(((size_t)b * 18 + st) * g.K + k) * g.C + c] : 0.f;
+            float sum = 0.f;
+            for (int tap = 0; tap < 9; ++tap) {
+                float v = (k < g.K && c < g.C) ? D[(((size_t)b * 18 + s * 9 + tap) * g.K + k) * g.C + c] : 0.f;
+                sD[((s * 9 + tap) * K1 + k) * 64 + cl] = v;
+                sum += v;
+            }
+            sDsum[i] = sum;
         }
+    }
     for (int i = threadIdx.x; i < (SF_TH + 2) * (SF_TW + 2); i += blockDim.x) {
         int gy = y0 + i / (SF_TW + 2) - 1, gx = x0 + i % (SF_TW + 2) - 1;
         unsigned char v = (unsigned char)g.K;
         if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = region[((size_t)b * g.H + gy) * g.W + gx];
         sR[i] = v;
+    }
+}
+
+// region indices of the 3x3 window of tile-local pixel (ly, lx); returns true when all nine are equal
+__device__ __forceinline__ bool sean_window(const unsigned char* sR, int ly, int lx, int (&kk)[9]) {
+    bool same = true;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        kk[tap] = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) same = same && (kk[tap] == kk[4]);
+    return same;
+}
+
+__device__ __forceinline__ void sean_gamma_beta1(const float* sD, const float* sDsum, int K1, const int (&kk)[9],
+                                                 bool wave_uniform, int cq, float4 bg, float4 bb, float4& g1,
+                                                 float4& b1) {
+    if (wave_uniform) {
+        g1 = f4add(bg, *(const float4*)(sDsum + (0 * K1 + kk[4]) * 64 + 4 * cq));
+        b1 = f4add(bb, *(const float4*)(sDsum + (1 * K1 + kk[4]) * 64 + 4 * cq));
+    } else {
+        g1 = bg;
+        b1 = bb;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + kk[tap]) * 64 + 4 * cq));
+            b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + kk[tap]) * 64 + 4 * cq));
+        }
     }
 }
 
@@ -335,44 +375,48 @@ __global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float
     DASR_DYN_SMEM(smem);
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                                  // [18][K+1][64]
-    unsigned char* sR = (unsigned char*)(sD + 18 * K1 * 64);   // [(TH+2)*(TW+2)]
+    float* sDsum = sD + 18 * K1 * 64;                          // [2][K+1][64]
+    unsigned char* sR = (unsigned char*)(sDsum + 2 * K1 * 64); // [(TH+2)*(TW+2)]
     const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
     const int x0 = (blockIdx.x % tiles_x) * SF_TW, y0 = (blockIdx.x / tiles_x) * SF_TH;
     const int b = blockIdx.y, c0 = blockIdx.z * 64;
-    sean_stage_onehot(g, region, D, sD, sR, b, c0, y0, x0, true);
+    sean_stage_onehot(g, region, D, sD, sDsum, sR, b, c0, y0, x0, true);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cq = lane & 15, ps = lane >> 4;
     const int c = c0 + 4 * cq;
-    if (c >= g.C) return;
+    const bool live = c < g.C;
     const float a_g = alpha_g[0], a_b = alpha_b[0];
-    const float4 mu = *(const float4*)(mean + (size_t)b * g.C + c);
-    const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
-    const float4 sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
-                                  dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
-    const float4 bg = *(const float4*)(bias_g + c), bb = *(const float4*)(bias_b + c);
-    // wave wv owns tile rows wv and wv+4; a wave-instruction covers 4 consecutive pixels of a row
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, bg = mu, bb = mu;
+    if (live) {
+        mu = *(const float4*)(mean + (size_t)b * g.C + c);
+        const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
+        sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
+                         dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
+        bg = *(const float4*)(bias_g + c);
+        bb = *(const float4*)(bias_b + c);
+    }
+    // wave wv owns tile rows wv, wv+4, ...; a wave-instruction covers 4 consecutive pixels of a row
 #pragma unroll 1
-    for (int rr = 0; rr < 2; ++rr) {
-        const int ly = wv + 4 * rr, y = y0 + ly;
-        if (y >= g.H) continue;
+    for (int ly = wv; ly < SF_TH; ly += 4) {
+        const int y = y0 + ly;
+        if (y >= g.H) break;
 #pragma unroll 2
         for (int xs = 0; xs < SF_TW / 4; ++xs) {
             const int lx = 4 * xs + ps, x = x0 + lx;
-            if (x >= g.W) continue;
+            const bool inb = live && x < g.W;
+            int kk[9];
+            const bool same = sean_window(sR, ly, lx, kk);
+            const bool wave_uniform = __all(same || !inb);
+            if (!inb) continue;
             const size_t p = ((size_t)b * g.H + y) * g.W + x;
             const float4 tv = *(const float4*)(t + p * g.C + c);
             const float4 g2 = *(const float4*)(gb2 + p * 2 * g.C + c);
             const float4 b2 = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
             float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (residual) rv = *(const float4*)(residual + p * g.C + c);
-            float4 g1 = bg, b1 = bb;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int k = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
-                g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k) * 64 + 4 * cq));
-                b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k) * 64 + 4 * cq));
-            }
+            float4 g1, b1;
+            sean_gamma_beta1(sD, sDsum, K1, kk, wave_uniform, cq, bg, bb, g1, b1);
             float4 o;
             o.x = (tv.x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x) + a_b * b1.x + (1.f - a_b) * b2.x + rv.x;
             o.y = (tv.y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y) + a_b * b1.y + (1.f - a_b) * b2.y + rv.y;
@@ -389,15 +433,17 @@ __global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float
 
 // ---- backward, pass A, one-hot -------------------------------------------------------------------------
 // 512 threads (8 waves, wave w = tile row w); a workgroup walks several tiles of ONE sample and keeps the
-// dynamic-kernel gradient in LDS: the contribution G[p] = (a_g*dgamma, a_b*dbeta) is added to
-// dD[tap][r(p+tap)] with LDS float atomics (ds_add_f32), two copies of the accumulator (even / odd pixel
-// sub-lane) halving same-address collisions.  The workgroup writes its dD as a slab; k_sean_dD_reduce sums
-// the slabs in a fixed order.
-__device__ __forceinline__ void sean_scatter(float* sdD, int K1, int tap, int k, int cq, const float4& G1,
-                                             const float4& B1) {
-    float* pg = sdD + ((0 * 9 + tap) * K1 + k) * 64 + 4 * cq;
-    float* pb = sdD + ((1 * 9 + tap) * K1 + k) * 64 + 4 * cq;
-    atomicAdd(pg + 0, G1.x); atomicAdd(pg + 1, G1.y); atomicAdd(pg + 2, G1.z); atomicAdd(pg + 3, G1.w);
+// dynamic-kernel gradient in LDS.  The contribution G[p] = (a_g*dgamma, a_b*dbeta) belongs to
+// dD[tap][r(p+tap)] for the 9 taps.  LDS float atomics are slow on gfx950 (measured: ~3 cycles per LANE), so
+// they are kept off the common path:
+//     dD[tap][k] = T[k] + corr[tap][k],   T[k] = sum_{r(p)=k} G[p]   (tap-independent),
+//     corr[tap][k] gets +G at r(p+tap) and -G at r(p) only where r(p+tap) != r(p)   (region boundaries).
+// Each lane sums T in registers while the region of its pixels stays the same (a run) and flushes the run
+// with 8 LDS atomics only when the region changes; boundary pixels pay the correction atomics.
+// The workgroup writes T + corr as a slab; k_sean_dD_reduce sums the slabs in a fixed order.
+__device__ __forceinline__ void sean_lds_add8(float* base, const float4& G1, const float4& B1, int stride_s) {
+    atomicAdd(base + 0, G1.x); atomicAdd(base + 1, G1.y); atomicAdd(base + 2, G1.z); atomicAdd(base + 3, G1.w);
+    float* pb = base + stride_s;
     atomicAdd(pb + 0, B1.x); atomicAdd(pb + 1, B1.y); atomicAdd(pb + 2, B1.z); atomicAdd(pb + 3, B1.w);
 }
 
@@ -413,8 +459,10 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     DASR_DYN_SMEM(smem);
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                          // [18][K+1][64]
-    float* sdD = sD + 18 * K1 * 64;                    // [2 copies][18][K+1][64]
-    float* sred = sdD + 2 * 18 * K1 * 64;              // [8 waves][18 floats x 16 cq] reduction scratch
+    float* sDsum = sD + 18 * K1 * 64;                  // [2][K+1][64]
+    float* sCorr = sDsum + 2 * K1 * 64;                // [18][K+1][64]  boundary corrections
+    float* sT = sCorr + 18 * K1 * 64;                  // [2][K+1][64]   per-region totals
+    float* sred = sT + 2 * K1 * 64;                    // [8 waves][18][16] reduction scratch
     unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);
     const int b = blockIdx.y, c0 = blockIdx.z * 64;
     const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
@@ -422,8 +470,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     const int cq = lane & 15, ps = lane >> 4;
     const int c = c0 + 4 * cq;
     const bool live = c < g.C;
-    for (int i = threadIdx.x; i < 2 * 18 * K1 * 64; i += blockDim.x) sdD[i] = 0.f;
-    float* sdD_mine = sdD + (ps & 1) * 18 * K1 * 64;
+    for (int i = threadIdx.x; i < 20 * K1 * 64; i += blockDim.x) sCorr[i] = 0.f;   // sCorr and sT are contiguous
     const float a_g = alpha_g[0], a_b = alpha_b[0];
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, bg = mu, bb = mu;
     if (live) {
@@ -436,19 +483,25 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     }
     float4 S1 = make_float4(0.f, 0.f, 0.f, 0.f), S2 = S1, dbg = S1, dbb = S1;
     float dag = 0.f, dab = 0.f;
+    float4 runG = S1, runB = S1;   // run-length accumulator of T for region kcur
+    int kcur = g.K;
     bool first = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SF_TH;
         __syncthreads();
-        sean_stage_onehot(g, region, D, sD, sR, b, c0, y0, x0, first);
+        sean_stage_onehot(g, region, D, sD, sDsum, sR, b, c0, y0, x0, first);
         first = false;
         __syncthreads();
         const int ly = wv, y = y0 + ly;
-        if (!live || y >= g.H) continue;
+        if (y >= g.H) continue;
 #pragma unroll 1
         for (int xs = 0; xs < SF_TW / 4; ++xs) {
             const int lx = 4 * xs + ps, x = x0 + lx;
-            if (x >= g.W) continue;
+            const bool inb = live && x < g.W;
+            int kk[9];
+            const bool same = sean_window(sR, ly, lx, kk);
+            const bool wave_uniform = __all(same || !inb);
+            if (!inb) continue;
             const size_t p = ((size_t)b * g.H + y) * g.W + x;
             float4 g0 = *(const float4*)(dout + p * g.C + c);
             if (relu) {
@@ -460,15 +513,8 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             const float4 tv = *(const float4*)(t + p * g.C + c);
             const float4 g2 = *(const float4*)(gb2 + p * 2 * g.C + c);
             const float4 b2 = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
-            float4 g1 = bg, b1 = bb;
-            int kk[9];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int k = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
-                kk[tap] = k;
-                g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k) * 64 + 4 * cq));
-                b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k) * 64 + 4 * cq));
-            }
+            float4 g1, b1;
+            sean_gamma_beta1(sD, sDsum, K1, kk, wave_uniform, cq, bg, bb, g1, b1);
             const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
             const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
             const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
@@ -482,8 +528,26 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             const float4 B1 = make_float4(a_b * g0.x, a_b * g0.y, a_b * g0.z, a_b * g0.w);
             dbg = f4add(dbg, G1);
             dbb = f4add(dbb, B1);
+            // T[r(p)] via the run accumulator
+            if (kk[4] != kcur) {
+                sean_lds_add8(sT + kcur * 64 + 4 * cq, runG, runB, K1 * 64);
+                kcur = kk[4];
+                runG = G1;
+                runB = B1;
+            } else {
+                runG = f4add(runG, G1);
+                runB = f4add(runB, B1);
+            }
+            // boundary corrections
+            if (!same) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) sean_scatter(sdD_mine, K1, tap, kk[tap], cq, G1, B1);
+                for (int tap = 0; tap < 9; ++tap) {
+                    if (kk[tap] != kk[4]) {
+                        sean_lds_add8(sCorr + (tap * K1 + kk[tap]) * 64 + 4 * cq, G1, B1, 9 * K1 * 64);
+                        sean_lds_add8(sCorr + (tap * K1 + kk[4]) * 64 + 4 * cq, f4neg(G1), f4neg(B1), 9 * K1 * 64);
+                    }
+                }
+            }
             float4 dxh;
             dxh.x = g0.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x);
             dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
@@ -495,6 +559,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
         }
     }
+    if (live) sean_lds_add8(sT + kcur * 64 + 4 * cq, runG, runB, K1 * 64);
     // reduce the per-channel sums over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
     float vals[18] = {S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, dbg.x, dbg.y, dbg.z, dbg.w,
                       dbb.x, dbb.y, dbb.z, dbb.w, dag, dab};
@@ -534,13 +599,12 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             atomicAdd(dalpha_b, rb);
         }
     }
-    // slab [b][blockIdx.x][18][K][C-slice]
+    // slab [b][blockIdx.x][18][K][C-slice] = T + corr
     float* slab = dD_slabs + ((size_t)b * gridDim.x + blockIdx.x) * 18 * g.K * g.C;
     for (int i = threadIdx.x; i < 18 * g.K * 64; i += blockDim.x) {
-        int cl = i & 63, r = i >> 6, k = r % g.K, st = r / g.K;
+        int cl = i & 63, r = i >> 6, k = r % g.K, st = r / g.K, s = st / 9;
         if (c0 + cl < g.C)
-            slab[((size_t)st * g.K + k) * g.C + c0 + cl] =
-                sdD[(st * K1 + k) * 64 + cl] + sdD[18 * K1 * 64 + (st * K1 + k) * 64 + cl];
+            slab[((size_t)st * g.K + k) * g.C + c0 + cl] = sCorr[(st * K1 + k) * 64 + cl] + sT[(s * K1 + k) * 64 + cl];
     }
 }
 
@@ -579,7 +643,7 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
     const bool fast = region != nullptr && (C % 4) == 0;
     if (fast) {
         int tiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
-        size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
+        size_t lds = sizeof(float) * (size_t)(20 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
         DASR_LAUNCH(k_sean_fwd_onehot, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2,
                     region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps);
     }
@@ -627,7 +691,7 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
     if (fast) {
         int nblk = sean_bwd_blocks_per_sample(B, H, W);
         int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
-        size_t lds = sizeof(float) * (size_t)(3 * 18 * (K + 1) * 64 + 8 * 18 * 16) + (SF_TH + 2) * (SF_TW + 2);
+        size_t lds = sizeof(float) * (size_t)(40 * (K + 1) * 64 + 8 * 18 * 16) + (SF_TH + 2) * (SF_TW + 2);
         DASR_LAUNCH(k_sean_bwd_a_onehot, dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t, mean,
                     var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
                     dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);

@@ -90,6 +90,21 @@ static inline T __shfl(T v, int src, int width = 64) {
     return hipemu_xchg(v, (l / width) * width + (src % width));
 }
 
+static inline int __all(int pred) {
+    int* buf = (int*)hipemu::wave_buf();
+    int l = hipemu::lane_id();
+    buf[l] = 2 + (pred ? 1 : 0);               // 2 marks "this lane voted in this round"
+    hipemu::wave_barrier();
+    int r = 1;
+    for (int i = 0; i < 64; ++i)
+        if (buf[i] == 2) r = 0;
+    hipemu::wave_barrier();
+    buf[l] = 0;                                // exited / absent lanes never vote: their slot stays 0 = ignored
+    hipemu::wave_barrier();
+    return r;
+}
+static inline int __any(int pred) { return !__all(!pred); }
+
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
