@@ -300,66 +300,48 @@ extern "C" int dasr_mask_compress(const float* mask, unsigned char* region, int*
 }
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4neg(float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
 
-// LDS carve of the one-hot kernels (floats): sD [18][K+1][64] | sDsum [2][K+1][64] (sum over the 9 taps)
-// Row K of every table is zero ("no region": outside the image or a pixel no mask claims).
-// Most pixels sit inside a region: all 9 neighbours carry the same index k0 and the dynamic conv collapses
-// to ONE row read, gamma1 = bias + Dsum[0][k0].  Only waves that touch a region boundary gather 9 rows.
-__device__ __forceinline__ void sean_stage_onehot(const SeanGeom& g, const unsigned char* __restrict__ region,
-                                                  const float* __restrict__ D, float* sD, float* sDsum,
-                                                  unsigned char* sR, int b, int c0, int y0, int x0, bool stage_D) {
+// Stage D[b] (channel slice c0..c0+63) as [18][K+1][64] with a zero row K ("no region": outside the image
+// or a pixel no mask claims); float4 copies, 16 threads per 64-channel row.
+__device__ __forceinline__ void sean_stage_D(const SeanGeom& g, const float* __restrict__ D, float* sD, int b, int c0) {
     const int K1 = g.K + 1;
-    if (stage_D) {
-        for (int i = threadIdx.x; i < 2 * K1 * 64; i += blockDim.x) {
-            int cl = i & 63, k = (i >> 6) % K1, s = i / (64 * K1);
-            int c = c0 + cl;
-            float sum = 0.f;
-            for (int tap = 0; tap < 9; ++tap) {
-                float v = (k < g.K && c < g.C) ? D[(((size_t)b * 18 + s * 9 + tap) * g.K + k) * g.C + c] : 0.f;
-                sD[((s * 9 + tap) * K1 + k) * 64 + cl] = v;
-                sum += v;
-            }
-            sDsum[i] = sum;
+    const int q = threadIdx.x & 15;
+    for (int r = threadIdx.x >> 4; r < 18 * K1; r += blockDim.x >> 4) {
+        const int st = r / K1, k = r - st * K1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < g.K) {
+            const float* src = D + (((size_t)b * 18 + st) * g.K + k) * g.C + c0 + 4 * q;
+            if (c0 + 4 * q + 3 < g.C) v = *(const float4*)src;
         }
+        *(float4*)(sD + r * 64 + 4 * q) = v;
     }
-    for (int i = threadIdx.x; i < (SF_TH + 2) * (SF_TW + 2); i += blockDim.x) {
+}
+// region tile with a 1-pixel halo; TH rows x SF_TW columns
+__device__ __forceinline__ void sean_stage_R(const SeanGeom& g, const unsigned char* __restrict__ region,
+                                             unsigned char* sR, int b, int y0, int x0, int TH) {
+    for (int i = threadIdx.x; i < (TH + 2) * (SF_TW + 2); i += blockDim.x) {
         int gy = y0 + i / (SF_TW + 2) - 1, gx = x0 + i % (SF_TW + 2) - 1;
         unsigned char v = (unsigned char)g.K;
         if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = region[((size_t)b * g.H + gy) * g.W + gx];
         sR[i] = v;
     }
 }
-
-// region indices of the 3x3 window of tile-local pixel (ly, lx); returns true when all nine are equal
-__device__ __forceinline__ bool sean_window(const unsigned char* sR, int ly, int lx, int (&kk)[9]) {
-    bool same = true;
+// gamma1 / beta1 of tile-local pixel (ly, lx): 9 row gathers from sD
+__device__ __forceinline__ void sean_gather(const float* sD, const unsigned char* sR, int K1, int ly, int lx, int cq,
+                                            float4 bg, float4 bb, float4& g1, float4& b1) {
+    g1 = bg;
+    b1 = bb;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        kk[tap] = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
-    }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) same = same && (kk[tap] == kk[4]);
-    return same;
-}
-
-__device__ __forceinline__ void sean_gamma_beta1(const float* sD, const float* sDsum, int K1, const int (&kk)[9],
-                                                 bool wave_uniform, int cq, float4 bg, float4 bb, float4& g1,
-                                                 float4& b1) {
-    if (wave_uniform) {
-        g1 = f4add(bg, *(const float4*)(sDsum + (0 * K1 + kk[4]) * 64 + 4 * cq));
-        b1 = f4add(bb, *(const float4*)(sDsum + (1 * K1 + kk[4]) * 64 + 4 * cq));
-    } else {
-        g1 = bg;
-        b1 = bb;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + kk[tap]) * 64 + 4 * cq));
-            b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + kk[tap]) * 64 + 4 * cq));
-        }
+        const int k = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
+        g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k) * 64 + 4 * cq));
+        b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k) * 64 + 4 * cq));
     }
 }
 
+// Forward.  Workgroup = 256 threads, tile = 8 rows x 32 columns; wave w owns rows w and w+4.  Per row the wave
+// issues the global loads of four 4-pixel steps (16 pixels) before it consumes any, so ~16 KiB per wave are in
+// flight; a lane holds 4 channels of one pixel (float4), a wave-instruction moves 4 x 256 B contiguous.
 __global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float* __restrict__ t,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          const float* __restrict__ gb2,
@@ -375,77 +357,80 @@ __global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float
     DASR_DYN_SMEM(smem);
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                                  // [18][K+1][64]
-    float* sDsum = sD + 18 * K1 * 64;                          // [2][K+1][64]
-    unsigned char* sR = (unsigned char*)(sDsum + 2 * K1 * 64); // [(TH+2)*(TW+2)]
+    unsigned char* sR = (unsigned char*)(sD + 18 * K1 * 64);   // [(TH+2)*(TW+2)]
     const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
     const int x0 = (blockIdx.x % tiles_x) * SF_TW, y0 = (blockIdx.x / tiles_x) * SF_TH;
     const int b = blockIdx.y, c0 = blockIdx.z * 64;
-    sean_stage_onehot(g, region, D, sD, sDsum, sR, b, c0, y0, x0, true);
+    sean_stage_D(g, D, sD, b, c0);
+    sean_stage_R(g, region, sR, b, y0, x0, SF_TH);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cq = lane & 15, ps = lane >> 4;
     const int c = c0 + 4 * cq;
-    const bool live = c < g.C;
+    if (c >= g.C) return;
     const float a_g = alpha_g[0], a_b = alpha_b[0];
-    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, bg = mu, bb = mu;
-    if (live) {
-        mu = *(const float4*)(mean + (size_t)b * g.C + c);
-        const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
-        sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
-                         dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
-        bg = *(const float4*)(bias_g + c);
-        bb = *(const float4*)(bias_b + c);
-    }
-    // wave wv owns tile rows wv, wv+4, ...; a wave-instruction covers 4 consecutive pixels of a row
+    const float4 mu = *(const float4*)(mean + (size_t)b * g.C + c);
+    const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
+    const float4 sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
+                                  dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
+    const float4 bg = *(const float4*)(bias_g + c), bb = *(const float4*)(bias_b + c);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
     for (int ly = wv; ly < SF_TH; ly += 4) {
         const int y = y0 + ly;
         if (y >= g.H) break;
-#pragma unroll 2
-        for (int xs = 0; xs < SF_TW / 4; ++xs) {
-            const int lx = 4 * xs + ps, x = x0 + lx;
-            const bool inb = live && x < g.W;
-            int kk[9];
-            const bool same = sean_window(sR, ly, lx, kk);
-            const bool wave_uniform = __all(same || !inb);
-            if (!inb) continue;
-            const size_t p = ((size_t)b * g.H + y) * g.W + x;
-            const float4 tv = *(const float4*)(t + p * g.C + c);
-            const float4 g2 = *(const float4*)(gb2 + p * 2 * g.C + c);
-            const float4 b2 = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
-            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (residual) rv = *(const float4*)(residual + p * g.C + c);
-            float4 g1, b1;
-            sean_gamma_beta1(sD, sDsum, K1, kk, wave_uniform, cq, bg, bb, g1, b1);
-            float4 o;
-            o.x = (tv.x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x) + a_b * b1.x + (1.f - a_b) * b2.x + rv.x;
-            o.y = (tv.y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y) + a_b * b1.y + (1.f - a_b) * b2.y + rv.y;
-            o.z = (tv.z - mu.z) * sc.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z) + a_b * b1.z + (1.f - a_b) * b2.z + rv.z;
-            o.w = (tv.w - mu.w) * sc.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w) + a_b * b1.w + (1.f - a_b) * b2.w + rv.w;
-            if (relu) {
-                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
-                o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+#pragma unroll 1
+        for (int hx = 0; hx < SF_TW; hx += 16) {
+            float4 tv[4], g2[4], b2[4], rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + hx + 4 * u + ps;
+                tv[u] = zero4; g2[u] = zero4; b2[u] = zero4; rv[u] = zero4;
+                if (x < g.W) {
+                    const size_t p = ((size_t)b * g.H + y) * g.W + x;
+                    tv[u] = *(const float4*)(t + p * g.C + c);
+                    g2[u] = *(const float4*)(gb2 + p * 2 * g.C + c);
+                    b2[u] = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
+                    if (residual) rv[u] = *(const float4*)(residual + p * g.C + c);
+                }
             }
-            *(float4*)(out + p * g.C + c) = o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int lx = hx + 4 * u + ps, x = x0 + lx;
+                if (x >= g.W) continue;
+                const size_t p = ((size_t)b * g.H + y) * g.W + x;
+                float4 g1, b1;
+                sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
+                float4 o;
+                o.x = (tv[u].x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * g2[u].x) + a_b * b1.x + (1.f - a_b) * b2[u].x + rv[u].x;
+                o.y = (tv[u].y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * g2[u].y) + a_b * b1.y + (1.f - a_b) * b2[u].y + rv[u].y;
+                o.z = (tv[u].z - mu.z) * sc.z * (1.f + a_g * g1.z + (1.f - a_g) * g2[u].z) + a_b * b1.z + (1.f - a_b) * b2[u].z + rv[u].z;
+                o.w = (tv[u].w - mu.w) * sc.w * (1.f + a_g * g1.w + (1.f - a_g) * g2[u].w) + a_b * b1.w + (1.f - a_b) * b2[u].w + rv[u].w;
+                if (relu) {
+                    o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                    o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+                }
+                *(float4*)(out + p * g.C + c) = o;
+            }
         }
     }
 }
 
 // ---- backward, pass A, one-hot -------------------------------------------------------------------------
-// 512 threads (8 waves, wave w = tile row w); a workgroup walks several tiles of ONE sample and keeps the
-// dynamic-kernel gradient in LDS.  The contribution G[p] = (a_g*dgamma, a_b*dbeta) belongs to
-// dD[tap][r(p+tap)] for the 9 taps.  LDS float atomics are slow on gfx950 (measured: ~3 cycles per LANE), so
-// they are kept off the common path:
-//     dD[tap][k] = T[k] + corr[tap][k],   T[k] = sum_{r(p)=k} G[p]   (tap-independent),
-//     corr[tap][k] gets +G at r(p+tap) and -G at r(p) only where r(p+tap) != r(p)   (region boundaries).
-// Each lane sums T in registers while the region of its pixels stays the same (a run) and flushes the run
-// with 8 LDS atomics only when the region changes; boundary pixels pay the correction atomics.
-// The workgroup writes T + corr as a slab; k_sean_dD_reduce sums the slabs in a fixed order.
-__device__ __forceinline__ void sean_lds_add8(float* base, const float4& G1, const float4& B1, int stride_s) {
-    atomicAdd(base + 0, G1.x); atomicAdd(base + 1, G1.y); atomicAdd(base + 2, G1.z); atomicAdd(base + 3, G1.w);
-    float* pb = base + stride_s;
-    atomicAdd(pb + 0, B1.x); atomicAdd(pb + 1, B1.y); atomicAdd(pb + 2, B1.z); atomicAdd(pb + 3, B1.w);
-}
+// The dynamic-kernel gradient  dD[s][tap][k][c] = sum_p [r(p+tap) == k] * G_s[p][c],  G = (a_g*dgamma, a_b*dbeta),
+// is a segmented reduction by region.  LDS float atomics are far too slow for it on gfx950 (measured ~3 cycles
+// per LANE), so it runs on the matrix cores instead: per tap, dD_tap = O_tap^T . G with O_tap the pixels x regions
+// one-hot matrix (built on the fly from the region bytes) — v_mfma_f32_16x16x4_f32 with M = region (<= 16),
+// N = 16 channels, K = 4 pixels.
+//
+// Workgroup = 512 threads (8 waves), tile = 4 rows x 32 columns, persistent over the tiles of ONE sample.
+//   phase 1 (all waves, elementwise): everything per pixel (dgb2, dres, dxhat -> dt, the per-channel sums) and
+//            G -> LDS tile sG [128 px][128 ch] (row stride 144 floats: conflict-free ds_read_b32 of the B operand)
+//   phase 2 (matrix cores): wave w accumulates tap w for all 128 channels (8 N-tiles) and N-tile w of tap 8:
+//            9 accumulators of 4 VGPRs, resident for the whole kernel.
+// At the end each workgroup writes its dD as a slab; k_sean_dD_reduce sums the slabs in a fixed order.
+#define SB_TH 4
+#define SB_GST 144
 
 __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     SeanGeom g, const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ t,
@@ -458,21 +443,19 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     if (*flag != 0) return;
     DASR_DYN_SMEM(smem);
     const int K1 = g.K + 1;
-    float* sD = (float*)smem;                          // [18][K+1][64]
-    float* sDsum = sD + 18 * K1 * 64;                  // [2][K+1][64]
-    float* sCorr = sDsum + 2 * K1 * 64;                // [18][K+1][64]  boundary corrections
-    float* sT = sCorr + 18 * K1 * 64;                  // [2][K+1][64]   per-region totals
-    float* sred = sT + 2 * K1 * 64;                    // [8 waves][18][16] reduction scratch
-    unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);
+    float* sD = (float*)smem;                                   // [18][K+1][64]
+    float* sG = sD + 18 * K1 * 64;                              // [SB_TH*SF_TW][SB_GST]
+    float* sred = sG + SB_TH * SF_TW * SB_GST;                  // [8 waves][18][16] reduction scratch
+    unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);   // [(SB_TH+2)*(SF_TW+2)]
     const int b = blockIdx.y, c0 = blockIdx.z * 64;
     const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cq = lane & 15, ps = lane >> 4;
     const int c = c0 + 4 * cq;
     const bool live = c < g.C;
-    for (int i = threadIdx.x; i < 20 * K1 * 64; i += blockDim.x) sCorr[i] = 0.f;   // sCorr and sT are contiguous
     const float a_g = alpha_g[0], a_b = alpha_b[0];
-    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, bg = mu, bb = mu;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 mu = zero4, sc = zero4, bg = zero4, bb = zero4;
     if (live) {
         mu = *(const float4*)(mean + (size_t)b * g.C + c);
         const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
@@ -481,86 +464,89 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
         bg = *(const float4*)(bias_g + c);
         bb = *(const float4*)(bias_b + c);
     }
-    float4 S1 = make_float4(0.f, 0.f, 0.f, 0.f), S2 = S1, dbg = S1, dbb = S1;
+    float4 S1 = zero4, S2 = zero4, dbg = zero4, dbb = zero4;
     float dag = 0.f, dab = 0.f;
-    float4 runG = S1, runB = S1;   // run-length accumulator of T for region kcur
-    int kcur = g.K;
-    bool first = true;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SF_TH;
-        __syncthreads();
-        sean_stage_onehot(g, region, D, sD, sDsum, sR, b, c0, y0, x0, first);
-        first = false;
-        __syncthreads();
-        const int ly = wv, y = y0 + ly;
-        if (y >= g.H) continue;
-#pragma unroll 1
-        for (int xs = 0; xs < SF_TW / 4; ++xs) {
-            const int lx = 4 * xs + ps, x = x0 + lx;
-            const bool inb = live && x < g.W;
-            int kk[9];
-            const bool same = sean_window(sR, ly, lx, kk);
-            const bool wave_uniform = __all(same || !inb);
-            if (!inb) continue;
-            const size_t p = ((size_t)b * g.H + y) * g.W + x;
-            float4 g0 = *(const float4*)(dout + p * g.C + c);
-            if (relu) {
-                const float4 ov = *(const float4*)(out + p * g.C + c);
-                g0.x = ov.x > 0.f ? g0.x : 0.f; g0.y = ov.y > 0.f ? g0.y : 0.f;
-                g0.z = ov.z > 0.f ? g0.z : 0.f; g0.w = ov.w > 0.f ? g0.w : 0.f;
-            }
-            if (dres) *(float4*)(dres + p * g.C + c) = g0;
-            const float4 tv = *(const float4*)(t + p * g.C + c);
-            const float4 g2 = *(const float4*)(gb2 + p * 2 * g.C + c);
-            const float4 b2 = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
-            float4 g1, b1;
-            sean_gamma_beta1(sD, sDsum, K1, kk, wave_uniform, cq, bg, bb, g1, b1);
-            const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
-            const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
-            const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
-            *(float4*)(dgb2 + p * 2 * g.C + c) =
-                make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y, (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w);
-            *(float4*)(dgb2 + p * 2 * g.C + g.C + c) =
-                make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y, (1.f - a_b) * g0.z, (1.f - a_b) * g0.w);
-            dag += dgam.x * (g1.x - g2.x) + dgam.y * (g1.y - g2.y) + dgam.z * (g1.z - g2.z) + dgam.w * (g1.w - g2.w);
-            dab += g0.x * (b1.x - b2.x) + g0.y * (b1.y - b2.y) + g0.z * (b1.z - b2.z) + g0.w * (b1.w - b2.w);
-            const float4 G1 = make_float4(a_g * dgam.x, a_g * dgam.y, a_g * dgam.z, a_g * dgam.w);
-            const float4 B1 = make_float4(a_b * g0.x, a_b * g0.y, a_b * g0.z, a_b * g0.w);
-            dbg = f4add(dbg, G1);
-            dbb = f4add(dbb, B1);
-            // T[r(p)] via the run accumulator
-            if (kk[4] != kcur) {
-                sean_lds_add8(sT + kcur * 64 + 4 * cq, runG, runB, K1 * 64);
-                kcur = kk[4];
-                runG = G1;
-                runB = B1;
-            } else {
-                runG = f4add(runG, G1);
-                runB = f4add(runB, B1);
-            }
-            // boundary corrections
-            if (!same) {
+    f32x4 acc[9];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    if (kk[tap] != kk[4]) {
-                        sean_lds_add8(sCorr + (tap * K1 + kk[tap]) * 64 + 4 * cq, G1, B1, 9 * K1 * 64);
-                        sean_lds_add8(sCorr + (tap * K1 + kk[4]) * 64 + 4 * cq, f4neg(G1), f4neg(B1), 9 * K1 * 64);
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = 0.f;
+    sean_stage_D(g, D, sD, b, c0);
+    const int mydy = wv / 3, mydx = wv % 3;     // tap of this wave (taps 0..7); tap 8 = (2,2) is shared
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
+        __syncthreads();                          // previous phase 2 is done with sG / sR
+        sean_stage_R(g, region, sR, b, y0, x0, SB_TH);
+        __syncthreads();
+        // ---- phase 1: wave w -> row w>>1, columns 16*(w&1) .. +15, four 4-pixel steps
+        {
+            const int ly = wv >> 1, y = y0 + ly;
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) {
+                const int lx = 16 * (wv & 1) + 4 * u + ps, x = x0 + lx;
+                float4 G1 = zero4, B1 = zero4;
+                if (live && y < g.H && x < g.W) {
+                    const size_t p = ((size_t)b * g.H + y) * g.W + x;
+                    float4 g0 = *(const float4*)(dout + p * g.C + c);
+                    if (relu) {
+                        const float4 ov = *(const float4*)(out + p * g.C + c);
+                        g0.x = ov.x > 0.f ? g0.x : 0.f; g0.y = ov.y > 0.f ? g0.y : 0.f;
+                        g0.z = ov.z > 0.f ? g0.z : 0.f; g0.w = ov.w > 0.f ? g0.w : 0.f;
                     }
+                    if (dres) *(float4*)(dres + p * g.C + c) = g0;
+                    const float4 tv = *(const float4*)(t + p * g.C + c);
+                    const float4 g2 = *(const float4*)(gb2 + p * 2 * g.C + c);
+                    const float4 b2 = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
+                    float4 g1, b1;
+                    sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
+                    const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
+                    const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
+                    const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
+                    *(float4*)(dgb2 + p * 2 * g.C + c) = make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y,
+                                                                    (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w);
+                    *(float4*)(dgb2 + p * 2 * g.C + g.C + c) = make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y,
+                                                                          (1.f - a_b) * g0.z, (1.f - a_b) * g0.w);
+                    dag += dgam.x * (g1.x - g2.x) + dgam.y * (g1.y - g2.y) + dgam.z * (g1.z - g2.z) +
+                           dgam.w * (g1.w - g2.w);
+                    dab += g0.x * (b1.x - b2.x) + g0.y * (b1.y - b2.y) + g0.z * (b1.z - b2.z) + g0.w * (b1.w - b2.w);
+                    G1 = make_float4(a_g * dgam.x, a_g * dgam.y, a_g * dgam.z, a_g * dgam.w);
+                    B1 = make_float4(a_b * g0.x, a_b * g0.y, a_b * g0.z, a_b * g0.w);
+                    dbg = f4add(dbg, G1);
+                    dbb = f4add(dbb, B1);
+                    float4 dxh;
+                    dxh.x = g0.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x);
+                    dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
+                    dxh.z = g0.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z);
+                    dxh.w = g0.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w);
+                    *(float4*)(dt + p * g.C + c) = dxh;
+                    S1 = f4add(S1, dxh);
+                    S2.x = fmaf(dxh.x, xc.x, S2.x); S2.y = fmaf(dxh.y, xc.y, S2.y);
+                    S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
                 }
+                float* gp = sG + (ly * SF_TW + lx) * SB_GST + 4 * cq;
+                *(float4*)gp = G1;                 // channels 0..63: gamma part
+                *(float4*)(gp + 64) = B1;          // channels 64..127: beta part
             }
-            float4 dxh;
-            dxh.x = g0.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x);
-            dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
-            dxh.z = g0.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z);
-            dxh.w = g0.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w);
-            *(float4*)(dt + p * g.C + c) = dxh;
-            S1 = f4add(S1, dxh);
-            S2.x = fmaf(dxh.x, xc.x, S2.x); S2.y = fmaf(dxh.y, xc.y, S2.y);
-            S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
+        }
+        __syncthreads();
+        // ---- phase 2: one-hot(region) x G on the matrix cores; 4 pixels per MFMA step
+        {
+            const int i16 = lane & 15, k4 = lane >> 4;
+#pragma unroll 2
+            for (int s = 0; s < SB_TH * SF_TW / 4; ++s) {
+                const int q = 4 * s + k4;                     // tile-local pixel of this lane's K slot
+                const int ly = q / SF_TW, lx = q % SF_TW;
+                const float a_my = (sR[(ly + mydy) * (SF_TW + 2) + lx + mydx] == i16) ? 1.f : 0.f;
+                const float a_8 = (sR[(ly + 2) * (SF_TW + 2) + lx + 2] == i16) ? 1.f : 0.f;
+                const float* gq = sG + q * SB_GST + i16;
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_my, gq[16 * nt], acc[nt], 0, 0, 0);
+                acc[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_8, gq[16 * wv], acc[8], 0, 0, 0);
+            }
         }
     }
-    if (live) sean_lds_add8(sT + kcur * 64 + 4 * cq, runG, runB, K1 * 64);
-    // reduce the per-channel sums over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
+    // ---- per-channel sums: reduce over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
     float vals[18] = {S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, dbg.x, dbg.y, dbg.z, dbg.w,
                       dbb.x, dbb.y, dbb.z, dbb.w, dag, dab};
 #pragma unroll
@@ -568,6 +554,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
         vals[q] += __shfl_xor(vals[q], 16, 64);
         vals[q] += __shfl_xor(vals[q], 32, 64);
     }
+    __syncthreads();
     if (ps == 0) {
 #pragma unroll
         for (int q = 0; q < 18; ++q) sred[(wv * 18 + q) * 16 + cq] = vals[q];
@@ -599,12 +586,22 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             atomicAdd(dalpha_b, rb);
         }
     }
-    // slab [b][blockIdx.x][18][K][C-slice] = T + corr
+    // ---- slab [b][blockIdx.x][18][K][C]: D fragment of the 16x16x4 MFMA: column = lane&15 (channel within the
+    // N-tile), row = 4*(lane>>4) + reg (region index)
     float* slab = dD_slabs + ((size_t)b * gridDim.x + blockIdx.x) * 18 * g.K * g.C;
-    for (int i = threadIdx.x; i < 18 * g.K * 64; i += blockDim.x) {
-        int cl = i & 63, r = i >> 6, k = r % g.K, st = r / g.K, s = st / 9;
-        if (c0 + cl < g.C)
-            slab[((size_t)st * g.K + k) * g.C + c0 + cl] = sCorr[(st * K1 + k) * 64 + cl] + sT[(s * K1 + k) * 64 + cl];
+    {
+        const int j = lane & 15;
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) {
+            const int tap = nt < 8 ? wv : 8;
+            const int ntile = nt < 8 ? nt : wv;            // 0..7: gamma channels 0..63 then beta channels 0..63
+            const int s = ntile >> 2, cc = c0 + 16 * (ntile & 3) + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * (lane >> 4) + r;
+                if (k < g.K && cc < g.C) slab[((size_t)(s * 9 + tap) * g.K + k) * g.C + cc] = acc[nt][r];
+            }
+        }
     }
 }
 
@@ -622,7 +619,7 @@ __global__ void __launch_bounds__(256) k_sean_dD_reduce(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------ host side
 static int sean_bwd_blocks_per_sample(int B, int H, int W) {
-    int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
+    int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + 4 - 1) / 4);
     int n = 256 / B;
     if (n < 1) n = 1;
     if (n > ntiles) n = ntiles;
@@ -643,7 +640,7 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
     const bool fast = region != nullptr && (C % 4) == 0;
     if (fast) {
         int tiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
-        size_t lds = sizeof(float) * (size_t)(20 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
+        size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
         DASR_LAUNCH(k_sean_fwd_onehot, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2,
                     region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps);
     }
@@ -690,8 +687,9 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
     const bool fast = region != nullptr && (C % 4) == 0;
     if (fast) {
         int nblk = sean_bwd_blocks_per_sample(B, H, W);
-        int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
-        size_t lds = sizeof(float) * (size_t)(40 * (K + 1) * 64 + 8 * 18 * 16) + (SF_TH + 2) * (SF_TW + 2);
+        int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SB_TH - 1) / SB_TH);
+        size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64 + SB_TH * SF_TW * SB_GST + 8 * 18 * 16) +
+                     (SB_TH + 2) * (SF_TW + 2);
         DASR_LAUNCH(k_sean_bwd_a_onehot, dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t, mean,
                     var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
                     dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
