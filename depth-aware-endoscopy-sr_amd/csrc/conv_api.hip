@@ -30,6 +30,7 @@ extern "C" int dasr_conv2d_fwd(const float* x, const float* w, const float* bias
     if (ps_r < 1) ps_r = 1;
     if (ps_r > 1 && (Cout % (ps_r * ps_r)) != 0) return DASR_E_SHAPE;
     if (conv_mfma_supported(g)) return conv_mfma_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
+    if (conv_c1_supported(g) && ps_r == 1 && !residual) return conv_c1_fwd(g, x, w, bias, y, act, stream);
     if (conv9_mfma_supported(g) && act == DASR_ACT_NONE && ps_r == 1 && !residual)
         return conv9_mfma_fwd(g, x, w, bias, y, stream);
     if (conv_gather_fwd_supported(g) && ps_r == 1 && !residual) return conv_gather_fwd(g, x, w, bias, y, act, stream);
@@ -76,6 +77,7 @@ extern "C" int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw, 
     ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
     int rc = check_geom(g);
     if (rc) return rc;
+    if (conv_c1_supported(g)) return conv_c1_wgrad(g, x, dconv, nullptr, DASR_ACT_NONE, dw, dbias, stream);
     if (conv_mfma_wgrad_supported(g)) {
         if (!workspace) return DASR_E_NULL;
         if (workspace_bytes < conv_mfma_wgrad_workspace(g)) return DASR_E_WORKSPACE;
@@ -94,4 +96,22 @@ extern "C" int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw, 
     if (rc) return rc;
     if (dbias) rc = conv_colsum(dconv, dbias, (size_t)B * Ho * Wo, Cout, stream);
     return rc;
+}
+
+extern "C" int dasr_conv2d_wgrad_act(const float* x, const float* dy, const float* y, float* dw, float* dbias,
+                                     float* dconv_scratch, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                                     int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                                     int transposed, int act, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(dy); DASR_CHECK_PTR(y); DASR_CHECK_PTR(dw);
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
+    if (conv_c1_supported(g)) return conv_c1_wgrad(g, x, dy, y, act, dw, dbias, stream);
+    // no fused kernel for this shape: materialise dconv, then the ordinary weight gradient
+    DASR_CHECK_PTR(dconv_scratch);
+    rc = conv_epilogue_bwd(g, dy, y, dconv_scratch, act, 1, stream);
+    if (rc) return rc;
+    return dasr_conv2d_wgrad(x, dconv_scratch, dw, dbias, workspace, workspace_bytes, B, H, W, Cin, Ho, Wo, Cout, KH, KW,
+                             stride, pad, transposed, stream);
 }

@@ -52,3 +52,9 @@ int conv_gather_dgrad(const ConvGeom& g, const float* dconv, const float* w, flo
 size_t conv_gather_wgrad_workspace(const ConvGeom& g);
 int conv_gather_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream);
 int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* stream);
+
+// conv_c1.hip (3x3, Cin == 1: SEAN.mlp_mask on the depth map)
+bool conv_c1_supported(const ConvGeom& g);
+int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream);
+int conv_c1_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* yact, int act, float* dw, float* dbias,
+                  void* stream);

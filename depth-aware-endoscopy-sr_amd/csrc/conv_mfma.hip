@@ -179,11 +179,11 @@ bool conv_mfma_dgrad_supported(const ConvGeom& g) {
 
 // ------------------------------------------------------------------------------------------ wgrad
 // Workgroup = 4 waves, owns a (32*MT) x (32*NTW) block of (ci, co) for all 9 taps and walks a strip of
-// 4 x 32 pixel tiles with the accumulators resident; K = pixels, two per MFMA step (h = lane>>5 picks the
+// 2 x 32 pixel tiles (51 KB of LDS: three workgroups per CU) with the accumulators resident; K = pixels, two per MFMA step (h = lane>>5 picks the
 // pixel of the pair).  A fragment: lane i reads channel ci0+i of pixel (p + off(tap)) -> 32 consecutive
 // floats per half-wave (conflict-free ds_read_b32); B fragment likewise from the dconv tile.  Each strip
 // writes its partial dW as a slab; k_wgrad_reduce sums the slabs in a fixed order (bitwise reproducible).
-#define WG_TH 4
+#define WG_TH 2
 #define WG_TW 32
 
 struct WgradArgs {

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float
                                                          const float* __restrict__ alpha_b,
                                                          const float* __restrict__ residual, float* __restrict__ out,
                                                          int relu, float eps) {
-    if (*flag != 0) return;   // masks are not one-hot: the general kernel does the work
+    if (flag && *flag != 0) return;   // masks are not one-hot: the general kernel does the work
     DASR_DYN_SMEM(smem);
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                                  // [18][K+1][64]
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     const float* __restrict__ alpha_b, float* __restrict__ dt, float* __restrict__ dgb2, float* __restrict__ dD_slabs,
     float* __restrict__ dbias_g, float* __restrict__ dbias_b, float* __restrict__ dalpha_g,
     float* __restrict__ dalpha_b, float* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
-    if (*flag != 0) return;
+    if (flag && *flag != 0) return;
     DASR_DYN_SMEM(smem);
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                                   // [18][K+1][64]
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
 
 __global__ void __launch_bounds__(256) k_sean_dD_reduce(const float* __restrict__ slabs, const int* __restrict__ flag,
                                                         float* __restrict__ dD, int per_sample, int nslab, size_t n) {
-    if (*flag != 0) return;
+    if (flag && *flag != 0) return;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         size_t b = i / per_sample, e = i % per_sample;
         const float* p = slabs + b * (size_t)nslab * per_sample + e;
@@ -633,21 +633,25 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
     DASR_CHECK_PTR(t); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var); DASR_CHECK_PTR(gb2); DASR_CHECK_PTR(mask);
     DASR_CHECK_PTR(D); DASR_CHECK_PTR(bias_g); DASR_CHECK_PTR(bias_b); DASR_CHECK_PTR(alpha_g); DASR_CHECK_PTR(alpha_b);
     DASR_CHECK_PTR(out);
-    if ((region == nullptr) != (onehot_flag == nullptr)) return DASR_E_NULL;
+    if (region == nullptr && onehot_flag != nullptr) return DASR_E_NULL;
     DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && C > 0 && K > 0);
     if (K > SEAN_MAXK) return DASR_E_UNSUPPORTED;
     SeanGeom g{B, H, W, C, K};
     const bool fast = region != nullptr && (C % 4) == 0;
+    const bool fast_only = fast && onehot_flag == nullptr;   // the caller vouches for one-hot masks
     if (fast) {
         int tiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
         DASR_LAUNCH(k_sean_fwd_onehot, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2,
                     region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps);
     }
-    int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
-    size_t lds = sizeof(float) * (size_t)(2 * 9 * K * 64 + K * (SEAN_TH + 2) * (SEAN_TW + 2));
-    DASR_LAUNCH(k_sean_fwd, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2, mask, D,
-                bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps, fast ? onehot_flag : (const int*)nullptr);
+    if (!fast_only) {
+        int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
+        size_t lds = sizeof(float) * (size_t)(2 * 9 * K * 64 + K * (SEAN_TH + 2) * (SEAN_TW + 2));
+        DASR_LAUNCH(k_sean_fwd, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2, mask, D,
+                    bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps,
+                    fast ? onehot_flag : (const int*)nullptr);
+    }
     DASR_RETURN_LAUNCH_STATUS();
 }
 
@@ -669,7 +673,7 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
     DASR_CHECK_PTR(alpha_g); DASR_CHECK_PTR(alpha_b); DASR_CHECK_PTR(dt); DASR_CHECK_PTR(dgb2); DASR_CHECK_PTR(dD);
     DASR_CHECK_PTR(dbias_g); DASR_CHECK_PTR(dbias_b); DASR_CHECK_PTR(dalpha_g); DASR_CHECK_PTR(dalpha_b);
     DASR_CHECK_PTR(workspace);
-    if ((region == nullptr) != (onehot_flag == nullptr)) return DASR_E_NULL;
+    if (region == nullptr && onehot_flag != nullptr) return DASR_E_NULL;
     DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && C > 0 && K > 0);
     if (K > SEAN_MAXK) return DASR_E_UNSUPPORTED;
     if (workspace_bytes < dasr_sean_bwd_workspace(B, H, W, C, K)) return DASR_E_WORKSPACE;
@@ -685,6 +689,7 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
     if ((e = hipMemsetAsync(dalpha_g, 0, sizeof(float), st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(dalpha_b, 0, sizeof(float), st)) != hipSuccess) return (int)e;
     const bool fast = region != nullptr && (C % 4) == 0;
+    const bool fast_only = fast && onehot_flag == nullptr;
     if (fast) {
         int nblk = sean_bwd_blocks_per_sample(B, H, W);
         int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SB_TH - 1) / SB_TH);
@@ -697,11 +702,13 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
         DASR_LAUNCH(k_sean_dD_reduce, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, (const float*)slabs, onehot_flag, dD,
                     18 * K * C, nblk, n);
     }
-    int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
-    size_t lds = sizeof(float) * (size_t)(2 * (2 * 9 * K * 64) + K * (SEAN_TH + 2) * (SEAN_TW + 2) + 6 * 256);
-    DASR_LAUNCH(k_sean_bwd_a, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, dout, out, t, mean, var, gb2,
-                mask, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, dD, dbias_g, dbias_b, dalpha_g, dalpha_b, dres, S,
-                relu, eps, fast ? onehot_flag : (const int*)nullptr);
+    if (!fast_only) {
+        int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
+        size_t lds = sizeof(float) * (size_t)(2 * (2 * 9 * K * 64) + K * (SEAN_TH + 2) * (SEAN_TW + 2) + 6 * 256);
+        DASR_LAUNCH(k_sean_bwd_a, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, dout, out, t, mean, var,
+                    gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, dD, dbias_g, dbias_b, dalpha_g, dalpha_b,
+                    dres, S, relu, eps, fast ? onehot_flag : (const int*)nullptr);
+    }
     size_t n = (size_t)B * H * W * C;
     DASR_LAUNCH(k_sean_bwd_b, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, t, mean, var, S, dt, H * W, C, n, eps);
     DASR_RETURN_LAUNCH_STATUS();

@@ -91,6 +91,14 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             return
         dy = out.grad
         out.grad = None
+        if not x.requires_grad and residual is None and ps_r == 1 and act != ops.ACT_NONE:
+            # leaf layer (the depth-map branch): activation backward fused into the weight gradient
+            dw, db = ops.conv2d_wgrad_act(x.data, dy, y, w.data.shape, act, stride, pad, transposed,
+                                          want_bias=bias is not None)
+            accum(w, dw)
+            if bias is not None:
+                accum(bias, db)
+            return
         if act != ops.ACT_NONE or ps_r > 1:
             dconv = ops.conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r)
         else:
@@ -198,7 +206,13 @@ class MaskPack:
 
     def __init__(self, planes):
         self.planes = planes
-        self.region, self.flag = ops.mask_compress(planes)
+        region, flag = ops.mask_compress(planes)
+        # one 4-byte read-back per forward: lets every SEAN call launch exactly one kernel.  (Pass the device flag
+        # through instead - both kernels launched, decision on the device - if the forward must not synchronise.)
+        if int(flag.item()) == 0:
+            self.region, self.flag = region, None
+        else:
+            self.region, self.flag = None, None
 
     @property
     def shape(self):

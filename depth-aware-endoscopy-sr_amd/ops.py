@@ -167,6 +167,23 @@ def conv2d_wgrad(x, dconv, w_shape, stride=1, pad=1, transposed=False, want_bias
     return dw, db
 
 
+def conv2d_wgrad_act(x, dy, y, w_shape, act, stride=1, pad=1, transposed=False, want_bias=True):
+    """Weight/bias gradient of a conv whose input needs no gradient, activation backward fused."""
+    B, H, W, Cin = x.shape
+    KH, KW, _, Cout = w_shape
+    _, Ho, Wo, _ = y.shape
+    lib = _lib.get()
+    nbytes = lib.dasr_conv2d_wgrad_workspace(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, int(transposed))
+    ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
+    fused = (Cin == 1 and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not transposed)
+    scratch = None if fused else torch.empty_like(y)
+    dw = empty(w_shape, x)
+    db = empty((Cout,), x) if want_bias else None
+    _call("dasr_conv2d_wgrad_act", _p(x), _p(dy), _p(y), _p(dw), _p(db, True), _p(scratch, True), _p(ws), nbytes, B, H,
+          W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, int(transposed), act)
+    return dw, db
+
+
 # ---- instance norm / SEAN -------------------------------------------------------------------
 def instnorm_stats(x):
     B, H, W, C = x.shape
@@ -213,7 +230,7 @@ def mask_compress(mask):
 def _rf(region, flag):
     if region is None:
         return None, None
-    return _lib.ptr(region, dtype=torch.uint8), _lib.ptr(flag, dtype=torch.int32)
+    return _lib.ptr(region, dtype=torch.uint8), (_lib.ptr(flag, dtype=torch.int32) if flag is not None else None)
 
 
 def sean_fwd(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu):

@@ -102,6 +102,14 @@ int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw_hwio, float*
                       size_t workspace_bytes, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
                       int stride, int pad, int transposed, void* stream);
 
+/* Weight/bias gradient with the activation backward fused in: dconv = dy * act'(y) is formed on the fly where a
+ * fused kernel exists (Cin == 1: SEAN.mlp_mask) and is materialised into dconv_scratch [B,Ho,Wo,Cout] otherwise
+ * (dconv_scratch may be NULL only for shapes with a fused kernel).  For layers whose input needs no gradient. */
+int dasr_conv2d_wgrad_act(const float* x, const float* dy, const float* y, float* dw_hwio, float* dbias,
+                          float* dconv_scratch, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin,
+                          int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int transposed, int act,
+                          void* stream);
+
 /* ---- instance-norm statistics ---------------------------------------------------------------
  * nn.InstanceNorm2d(affine=False) appears twice in a row on every DGB conv output
  * (sftmd_arch.py:811-820 then normalization.py:16-17,56).  Both collapse to one per-(b,c) scale:
@@ -140,7 +148,9 @@ int dasr_dynk_bwd(const float* dD, const float* st, const float* stp, const floa
  * t, out, residual: NHWC [B,H,W,C]; gb2: NHWC [B,H,W,2C] (gamma2 | beta2 = mlp_gamma_o | mlp_beta_o outputs);
  * mask: NCHW [B,K,H,W] as the reference delivers it (any float values); bias_gamma/bias_beta [C] are the
  * mlp_gamma_s / mlp_beta_s biases; alpha_gamma / alpha_beta are 1-element DEVICE tensors (trainable, normalization.py:30-35).
- * region / onehot_flag: outputs of dasr_mask_compress for the same mask (both NULL: general kernel only).
+ * region / onehot_flag: outputs of dasr_mask_compress for the same mask.  Both NULL: general kernel only.
+ * Both given: both kernels are launched and the flag decides ON THE DEVICE which one works.  region given and
+ * onehot_flag NULL: the caller has read the flag (== 0) itself and vouches for one-hot masks: gather kernel only.
  */
 /* One byte per pixel from the K mask planes: region[b,y,x] = k if mask[b,k,y,x] == 1 and every other plane is 0,
  * K if all planes are 0; *onehot_flag is set to a non-zero value if ANY pixel is neither (soft / overlapping

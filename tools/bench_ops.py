@@ -40,6 +40,7 @@ def main():
         _, _, _, mk = synth.seeded_batch(0, B, H, W, 1, K)
         mk = mk.to(dev)
         region, flag = ops.mask_compress(mk)
+        flag = None if int(flag.item()) == 0 else flag   # what graph.MaskPack does
         D = torch.randn(B, 2, 9, K, C, device=dev) * 0.1
         bg, bb = torch.randn(C, device=dev), torch.randn(C, device=dev)
         ag, ab = torch.full((1,), 0.7, device=dev), torch.full((1,), 0.74, device=dev)
