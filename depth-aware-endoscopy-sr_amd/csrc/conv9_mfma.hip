@@ -212,15 +212,16 @@ __global__ void __launch_bounds__(256) k_conv9x9_wgrad_mfma(Conv9Args a) {
         }
         c9_stage_dy(a, sDy, b, y0, x0, tid);
         __syncthreads();
-#pragma unroll 1
+#pragma unroll 2
         for (int s = 0; s < 2 * C9_TQ / 2; ++s) {       // this wave's 2 rows x 64 columns, two pixels per step
             const int r = 2 * wv + s / (C9_TQ / 2), qx = 2 * (s % (C9_TQ / 2)) + lh;
             const float av = sX[(r * C9_TQ + qx) * 32 + li];
+            const float* dyq = sDy + (r + 8) * C9_DYW + a.Cout * qx + li;
+            float bvv[9];
 #pragma unroll
-            for (int kh = 0; kh < 9; ++kh) {
-                const float bv = sDy[(r - kh + 8) * C9_DYW + a.Cout * qx + li];
-                acc[kh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh], 0, 0, 0);
-            }
+            for (int kh = 0; kh < 9; ++kh) bvv[kh] = dyq[-kh * C9_DYW];
+#pragma unroll
+            for (int kh = 0; kh < 9; ++kh) acc[kh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv[kh], acc[kh], 0, 0, 0);
         }
     }
     float* slab = a.out + ((size_t)(blockIdx.y * 4 + wv) * gridDim.x + blockIdx.x) * (9 * 32 * 32);

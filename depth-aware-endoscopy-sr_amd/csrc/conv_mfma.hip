@@ -237,27 +237,41 @@ __global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
             *(float4*)(sD + pix * COG + 4 * c4) = v;
         }
         __syncthreads();
+        // this wave's taps: tap(a) = a*G + grp (a < NACC); a slot past the ninth tap multiplies by zero
+        int aoff[NACC];
+        float amask[NACC];
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) {
+            const int tap = t * G + grp;
+            const int tt = tap < 9 ? tap : 0;
+            aoff[t] = ((tt / 3) * (WG_TW + 2) + tt % 3) * CIG + 32 * mt + li;
+            amask[t] = tap < 9 ? 1.f : 0.f;
+        }
 #pragma unroll 2
         for (int s = 0; s < WG_TH * WG_TW / 2; ++s) {
             const int py = s / (WG_TW / 2), px = 2 * (s % (WG_TW / 2)) + lh;
             const float bv = sD[(py * WG_TW + px) * COG + 32 * nt + li];
+            const float* xs = sX + (py * (WG_TW + 2) + px) * CIG;
+            float av[NACC];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                if (tap % G != grp) continue;
-                const int dy = tap / 3, dx = tap % 3;
-                const float av = sX[((py + dy) * (WG_TW + 2) + px + dx) * CIG + 32 * mt + li];
-                acc[tap / G] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap / G], 0, 0, 0);
+            for (int t = 0; t < NACC; ++t) av[t] = xs[aoff[t]];
+            if (G > 1) {
+#pragma unroll
+                for (int t = 0; t < NACC; ++t) av[t] *= amask[t];
             }
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
         }
     }
     float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        if (tap % G != grp) continue;
+    for (int t = 0; t < NACC; ++t) {
+        const int tap = t * G + grp;
+        if (tap >= 9) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int ci = ci0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = acc[tap / G][r];
+            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = acc[t][r];
         }
     }
 }
