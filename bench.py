@@ -72,15 +72,33 @@ class SeanTimer:
         return avg_ms, avg_bytes, len(ms)
 
 
-def cpu_baseline(frames=2, steps=2):
-    """CPU oracle (as-written PyTorch restatement of the reference, oracle/depthnet_oracle.py) on the host
-    cores: forward + losses + backward + Adam on `frames` frames of the same x8 workload."""
-    from oracle import depthnet_oracle as O
-    cores = os.cpu_count() or 1
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline(frames=1, steps=2):
+    """CPU oracle (as-written PyTorch restatement of the reference, oracle/depthnet_oracle.py) on the host
+    cores: forward + losses + backward + Adam on `frames` frame(s) of the same x8 workload."""
+    from oracle import depthnet_oracle as O
+    cores = min(host_cores(), 32)
     torch.set_num_threads(cores)
     cfg = O.make_cfg()
     sd = O.new_state_dict(cfg)
@@ -93,22 +111,24 @@ def cpu_baseline(frames=2, steps=2):
     times = []
     fwd_times = []
     for i in range(steps + 1):
-        print("[bench] cpu baseline step %d/%d" % (i, steps), file=sys.stderr, flush=True)
+        print("[bench] cpu baseline step %d/%d (%d threads)" % (i, steps, cores), file=sys.stderr, flush=True)
         t0 = time.perf_counter()
         optim.zero_grad(set_to_none=True)
         sr = O.depthnet_forward(sd, cfg, lq, dm, mk)
         t1 = time.perf_counter()
+        print("[bench]   forward %.1f s" % (t1 - t0), file=sys.stderr, flush=True)
         total, _, _, _ = O.total_loss(sr, gt, mk, w)
         total.backward()
         optim.step()
         t2 = time.perf_counter()
+        print("[bench]   loss+backward+Adam %.1f s" % (t2 - t1), file=sys.stderr, flush=True)
         if i > 0:                      # first step is the warm-up
             times.append(t2 - t0)
             fwd_times.append(t1 - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": frames / med, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames x8 128x160, 1 warm-up + %d timed fwd+loss+bwd+Adam steps of the CPU oracle "
+    return {"value": round(frames / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frame(s) x8 128x160, 1 warm-up + %d timed fwd+loss+bwd+Adam steps of the CPU oracle "
                       "(median); forward-only %.3f frames/s" % (frames, steps, frames / (sum(fwd_times) / len(fwd_times)))}
 
 
