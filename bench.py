@@ -94,7 +94,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(frames=1, steps=2):
+def cpu_baseline(frames=4, steps=2):
     """CPU oracle (as-written PyTorch restatement of the reference, oracle/depthnet_oracle.py) on the host
     cores: forward + losses + backward + Adam on `frames` frame(s) of the same x8 workload."""
     from oracle import depthnet_oracle as O
