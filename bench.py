@@ -204,7 +204,7 @@ def main():
     if s is not None:
         avg_ms, avg_bytes, n = s
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_sean_fwd (dasr_sean_fwd: DGB dynamic conv + DFN modulation, forward)",
+        roof = {"bound": "hbm", "kernel": "k_sean_fwd_onehot (dasr_sean_fwd: DGB dynamic conv + DFN modulation, forward)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches_timed": n,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes)}

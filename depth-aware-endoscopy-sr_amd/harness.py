@@ -135,7 +135,11 @@ class Trainer:
         total.backward()
         self._allreduce_grads()
         self.optimizer.step()
-        self.log = {"l_all": total.detach(), "l_pix": l_pix.detach(), "l_dynamic": l_dyn.detach()}
+        l_pix_log = l_pix.detach().clone()
+        if self.world > 1:                      # log the global-batch value (the gradient is already global)
+            torch.distributed.all_reduce(l_pix_log, group=self.group)
+            l_pix_log /= self.world
+        self.log = {"l_all": l_pix_log + l_dyn.detach(), "l_pix": l_pix_log, "l_dynamic": l_dyn.detach()}
         return self.log
 
     @torch.no_grad()
