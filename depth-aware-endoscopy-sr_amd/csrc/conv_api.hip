@@ -81,7 +81,7 @@ extern "C" int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw, 
     if (conv_mfma_wgrad_supported(g)) {
         if (!workspace) return DASR_E_NULL;
         if (workspace_bytes < conv_mfma_wgrad_workspace(g)) return DASR_E_WORKSPACE;
-        rc = conv_mfma_wgrad(g, x, dconv, dw, workspace, stream);
+        return conv_mfma_wgrad(g, x, dconv, dw, dbias, workspace, stream);
     } else if (conv9_mfma_supported(g)) {
         if (!workspace) return DASR_E_NULL;
         if (workspace_bytes < conv9_mfma_wgrad_workspace(g)) return DASR_E_WORKSPACE;

@@ -35,19 +35,44 @@ __device__ __forceinline__ bool gather_src(const GatherArgs& a, int oy, int ox, 
     return iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
 }
 
+// Output-pixel order.  For the "transposed" gather with stride s only every s-th row/column of taps lands on an
+// input pixel, and which taps do depends on (oy mod s, ox mod s).  Enumerating the output pixels class by class
+// (all pixels of one residue class are consecutive) makes tap validity uniform inside a 32-pixel M-tile, so a
+// wave can skip the dead taps (3 of 4 at stride 2) instead of multiplying zeros.
+__device__ __forceinline__ bool gather_pixel(int B, int Ho, int Wo, int stride, int by_class, size_t m, int& b,
+                                             int& oy, int& ox) {
+    const size_t M = (size_t)B * Ho * Wo;
+    if (m >= M) return false;
+    if (!by_class || stride <= 1) {
+        ox = (int)(m % Wo);
+        oy = (int)((m / Wo) % Ho);
+        b = (int)(m / ((size_t)Wo * Ho));
+        return true;
+    }
+    size_t rest = m;
+    for (int cy = 0; cy < stride; ++cy)
+        for (int cx = 0; cx < stride; ++cx) {
+            const int hc = (Ho - cy + stride - 1) / stride, wc = (Wo - cx + stride - 1) / stride;
+            const size_t cnt = (size_t)B * hc * wc;
+            if (rest < cnt) {
+                ox = cx + stride * (int)(rest % wc);
+                oy = cy + stride * (int)((rest / wc) % hc);
+                b = (int)(rest / ((size_t)wc * hc));
+                return true;
+            }
+            rest -= cnt;
+        }
+    return false;
+}
+
 template <int NT>
 __global__ void __launch_bounds__(256) k_conv_gather_mfma(GatherArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
     const size_t M = (size_t)a.B * a.Ho * a.Wo;
     const size_t m = ((size_t)blockIdx.x * 4 + wv) * 32 + li;      // this lane's output pixel (A row)
     const int n0 = blockIdx.y * 32 * NT;
-    const bool mvalid = m < M;
     int ox = 0, oy = 0, b = 0;
-    if (mvalid) {
-        ox = (int)(m % a.Wo);
-        oy = (int)((m / a.Wo) % a.Ho);
-        b = (int)(m / ((size_t)a.Wo * a.Ho));
-    }
+    const bool mvalid = gather_pixel(a.B, a.Ho, a.Wo, a.stride, a.gather, m, b, oy, ox);
     f32x16 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -57,6 +82,7 @@ __global__ void __launch_bounds__(256) k_conv_gather_mfma(GatherArgs a) {
         for (int kw = 0; kw < a.KW; ++kw) {
             int iy, ix;
             const bool ok = mvalid && gather_src(a, oy, ox, kh, kw, iy, ix);
+            if (!__any(ok)) continue;                       // dead tap for this whole M-tile
             const float* src = ok ? a.in + (((size_t)b * a.Hi + iy) * a.Wi + ix) * a.Kd : a.in;
             const int tap = kh * a.KW + kw;
             for (int c0 = 0; c0 < a.Kd; c0 += 8) {
@@ -91,9 +117,10 @@ __global__ void __launch_bounds__(256) k_conv_gather_mfma(GatherArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const size_t mm = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (mm >= M) continue;
+            int pb, py, px;
+            if (!gather_pixel(a.B, a.Ho, a.Wo, a.stride, a.gather, mm, pb, py, px)) continue;
             float v = dasr_act(acc[n][r] + bv, a.act);
-            const size_t o = mm * a.Nd + nn;
+            const size_t o = (((size_t)pb * a.Ho + py) * a.Wo + px) * a.Nd + nn;
             if (a.accumulate) v += a.out[o];
             a.out[o] = v;
         }
@@ -132,12 +159,13 @@ __global__ void __launch_bounds__(256) k_conv_gather_wgrad_mfma(GatherWgradArgs 
     for (size_t mb = m0; mb < m1; mb += 2) {
         const size_t m = mb + lh;
         float av = 0.f, b0 = 0.f, b1 = 0.f;
-        if (m < m1) {
-            const int ox = (int)(m % a.Wo), oy = (int)((m / a.Wo) % a.Ho), b = (int)(m / ((size_t)a.Wo * a.Ho));
-            int iy, ix;
-            if (gather_src(ga, oy, ox, kh, kw, iy, ix))
-                av = a.x[(((size_t)b * a.H + iy) * a.W + ix) * a.Cin + 32 * ct + li];
-            const float* dp = a.dy + m * a.Cout + 64 * cp + li;
+        int ox, oy, b, iy, ix;
+        const bool ok = m < m1 && gather_pixel(a.B, a.Ho, a.Wo, a.stride, a.transposed, m, b, oy, ox) &&
+                        gather_src(ga, oy, ox, kh, kw, iy, ix);
+        if (!__any(ok)) continue;                           // this tap reads no input pixel for these two outputs
+        if (ok) {
+            av = a.x[(((size_t)b * a.H + iy) * a.W + ix) * a.Cin + 32 * ct + li];
+            const float* dp = a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + 64 * cp + li;
             b0 = dp[0];
             b1 = dp[32];
         }

@@ -33,7 +33,8 @@ int conv_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float
                   float* y, int act, int ps_r, void* stream);
 int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
 size_t conv_mfma_wgrad_workspace(const ConvGeom& g);
-int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream);
+int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
+                    void* stream);   // dbias (may be null) is produced by the kernel itself
 
 // conv9_mfma.hip (9x9, pad 4, Cin % 32 == 0, Cout <= 3: the output convolution)
 bool conv9_mfma_supported(const ConvGeom& g);

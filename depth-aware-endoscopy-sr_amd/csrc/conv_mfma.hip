@@ -190,6 +190,7 @@ struct WgradArgs {
     const float* x;      // [B,H,W,Cin]
     const float* dy;     // [B,H,W,Cout]
     float* slabs;        // [P][9][Cin][Cout]
+    float* dbias;        // [Cout], zeroed by the host, or null: column sums of dy added by the ci-group-0 workgroups
     int B, H, W, Cin, Cout;
     int P, ntiles;
 };
@@ -215,6 +216,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool do_bias = a.dbias != nullptr && ci0 == 0 && tid < COG;
+    float bsum = 0.f;
 
     for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
@@ -237,6 +240,10 @@ __global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
             *(float4*)(sD + pix * COG + 4 * c4) = v;
         }
         __syncthreads();
+        if (do_bias) {                          // bias gradient: column sums of the staged dy tile
+#pragma unroll 8
+            for (int px = 0; px < WG_TH * WG_TW; ++px) bsum += sD[px * COG + tid];
+        }
         // this wave's taps: tap(a) = a*G + grp (a < NACC); a slot past the ninth tap multiplies by zero
         int aoff[NACC];
         float amask[NACC];
@@ -263,6 +270,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
             for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
         }
     }
+    if (do_bias) atomicAdd(&a.dbias[co0 + tid], bsum);
     float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
@@ -338,10 +346,15 @@ size_t conv_mfma_wgrad_workspace(const ConvGeom& g) {
     wgrad_plan(g, MT, NTW, groups, ntiles, P);
     return sizeof(float) * (size_t)P * 9 * g.Cin * g.Cout;
 }
-int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream) {
+int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
+                    void* stream) {
     int MT, NTW, groups, ntiles, P;
     wgrad_plan(g, MT, NTW, groups, ntiles, P);
-    WgradArgs a{x, dconv, (float*)workspace, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
+    if (dbias) {
+        hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * g.Cout, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    WgradArgs a{x, dconv, (float*)workspace, dbias, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
     size_t lds = sizeof(float) * (size_t)((WG_TH + 2) * (WG_TW + 2) * 32 * MT + WG_TH * WG_TW * 32 * NTW);
     dim3 grid(groups, P);
     if (MT == 2 && NTW == 2) {

@@ -15,18 +15,40 @@ __global__ void k_dynk_stp(const float* __restrict__ st, const float* __restrict
         stp[i] = acc;
     }
 }
-// D layout [B][2][9][K][C]
-__global__ void k_dynk_D(const float* __restrict__ stp, const float* __restrict__ Wg, const float* __restrict__ Wb,
-                         float* __restrict__ D, int K, int L, int C, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % C), k = (int)((i / C) % K), tap = (int)((i / ((size_t)C * K)) % 9);
-        int s = (int)((i / ((size_t)C * K * 9)) % 2);
-        size_t b = i / ((size_t)C * K * 18);
-        const float* Wp = (s ? Wb : Wg) + (size_t)c * L * 9 + tap;
-        const float* sp = stp + (b * K + k) * L;
-        float acc = 0.f;
-        for (int l = 0; l < L; ++l) acc = fmaf(Wp[(size_t)l * 9], sp[l], acc);
-        D[i] = acc;
+// The three contractions below are small GEMMs (M,N ~ 10^2..10^3, K = L, B*K or 18*C) over L2-resident operands.
+// One wave = one 32x32 output tile on v_mfma_f32_32x32x2_f32, operands gathered straight from global memory
+// (lane (i,h) supplies A[m0+i][2s+h] and B[2s+h][n0+i]); no LDS, no barriers.
+//
+// D[b,st,k,c] = sum_l stp[b,k,l] * W_s[c,l,tap]      M = (b,k), N = (st,c), K = l
+__global__ void __launch_bounds__(256) k_dynk_D_mfma(const float* __restrict__ stp, const float* __restrict__ Wg,
+                                                     const float* __restrict__ Wb, float* __restrict__ D, int B, int K,
+                                                     int L, int C) {
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int M = B * K, N = 18 * C;
+    const int tiles_n = (N + 31) / 32;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ((M + 31) / 32) * tiles_n) return;
+    const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+    const int m = m0 + li, n = n0 + li;
+    const bool mv = m < M, nv = n < N;
+    const int st = nv ? n / C : 0, c = nv ? n % C : 0;
+    const float* ap = stp + (size_t)(mv ? m : 0) * L;
+    const float* bp = (st >= 9 ? Wb : Wg) + (size_t)c * L * 9 + (st % 9);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int l = lh; l < L; l += 2) {
+        const float av = mv ? ap[l] : 0.f;
+        const float bv = nv ? bp[(size_t)l * 9] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (!nv) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (mm >= M) continue;
+        const int b = mm / K, k = mm % K;
+        D[(((size_t)b * 18 + st) * K + k) * C + c] = acc[r];
     }
 }
 extern "C" int dasr_dynk_fwd(const float* st, const float* A_w, const float* A_b, const float* Wg, const float* Wb,
@@ -36,36 +58,76 @@ extern "C" int dasr_dynk_fwd(const float* st, const float* A_w, const float* A_b
     DASR_CHECK_SHAPE(B > 0 && K > 0 && L > 0 && C > 0);
     size_t n1 = (size_t)B * K * L, n2 = (size_t)B * 18 * K * C;
     DASR_LAUNCH(k_dynk_stp, dim3(dasr_ew_grid(n1)), dim3(256), 0, stream, st, A_w, A_b, stp, K, L, n1);
-    DASR_LAUNCH(k_dynk_D, dim3(dasr_ew_grid(n2)), dim3(256), 0, stream, stp, Wg, Wb, D, K, L, C, n2);
+    (void)n2;
+    if ((L % 2) != 0) return DASR_E_UNSUPPORTED;
+    {
+        int tiles = ((B * K + 31) / 32) * ((18 * C + 31) / 32);
+        DASR_LAUNCH(k_dynk_D_mfma, dim3((tiles + 3) / 4), dim3(256), 0, stream, stp, Wg, Wb, D, B, K, L, C);
+    }
     DASR_RETURN_LAUNCH_STATUS();
 }
 
-// dW_s[c,l,tap] = sum_{b,k} dD[b,s,tap,k,c] * stp[b,k,l]
-__global__ void k_dynk_dW(const float* __restrict__ dD, const float* __restrict__ stp, float* __restrict__ dWg,
-                          float* __restrict__ dWb, int B, int K, int L, int C, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int tap = (int)(i % 9), l = (int)((i / 9) % L), c = (int)((i / ((size_t)9 * L)) % C);
-        int s = (int)(i / ((size_t)9 * L * C));
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            for (int k = 0; k < K; ++k)
-                acc = fmaf(dD[((((size_t)b * 2 + s) * 9 + tap) * K + k) * C + c], stp[((size_t)b * K + k) * L + l], acc);
-        (s ? dWb : dWg)[((size_t)c * L + l) * 9 + tap] = acc;
+// dW_s[c,l,tap] = sum_{(b,k)} dD[b,st,k,c] * stp[b,k,l]      M = (st,c), N = l, K = (b,k)
+__global__ void __launch_bounds__(256) k_dynk_dW_mfma(const float* __restrict__ dD, const float* __restrict__ stp,
+                                                      float* __restrict__ dWg, float* __restrict__ dWb, int B, int K,
+                                                      int L, int C) {
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int M = 18 * C, N = L, KK = B * K;
+    const int tiles_n = (N + 31) / 32;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ((M + 31) / 32) * tiles_n) return;
+    const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+    const int m = m0 + li, n = n0 + li;
+    const bool mv = m < M, nv = n < N;
+    const int st = mv ? m / C : 0, c = mv ? m % C : 0;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kk = lh; kk < KK + (KK & 1); kk += 2) {
+        float av = 0.f, bv = 0.f;
+        if (kk < KK) {
+            const int b = kk / K, k = kk % K;
+            if (mv) av = dD[(((size_t)b * 18 + st) * K + k) * C + c];
+            if (nv) bv = stp[(size_t)kk * L + n];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (!nv) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (mm >= M) continue;
+        const int st2 = mm / C, c2 = mm % C;
+        (st2 >= 9 ? dWb : dWg)[((size_t)c2 * L + n) * 9 + (st2 % 9)] = acc[r];
     }
 }
-// dstp[b,k,l] = sum_{s,tap,c} dD[b,s,tap,k,c] * W_s[c,l,tap]; blockIdx.y = (s,tap) slice, partial sums are
-// added with float atomics into the zeroed dstp (18 adds per element)
-__global__ void k_dynk_dstp(const float* __restrict__ dD, const float* __restrict__ Wg, const float* __restrict__ Wb,
-                            float* __restrict__ dstp, int K, int L, int C, size_t n) {
-    const int st = blockIdx.y, s = st / 9, tap = st % 9;
-    const float* Wp = s ? Wb : Wg;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int l = (int)(i % L), k = (int)((i / L) % K);
-        size_t b = i / ((size_t)L * K);
-        const float* dp = dD + ((b * 18 + st) * K + k) * C;
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc = fmaf(dp[c], Wp[((size_t)c * L + l) * 9 + tap], acc);
-        atomicAdd(&dstp[i], acc);
+// dstp[b,k,l] = sum_{(st,c)} dD[b,st,k,c] * W_s[c,l,tap]      M = (b,k), N = l, K = (st,c)
+__global__ void __launch_bounds__(256) k_dynk_dstp_mfma(const float* __restrict__ dD, const float* __restrict__ Wg,
+                                                        const float* __restrict__ Wb, float* __restrict__ dstp, int B,
+                                                        int K, int L, int C) {
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int M = B * K, N = L, KK = 18 * C;
+    const int tiles_n = (N + 31) / 32;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ((M + 31) / 32) * tiles_n) return;
+    const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+    const int m = m0 + li, n = n0 + li;
+    const bool mv = m < M, nv = n < N;
+    const int b = mv ? m / K : 0, k = mv ? m % K : 0;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kk = lh; kk < KK; kk += 2) {          // 18*C is even
+        const int st = kk / C, c = kk % C;
+        const float av = mv ? dD[(((size_t)b * 18 + st) * K + k) * C + c] : 0.f;
+        const float bv = nv ? (st >= 9 ? Wb : Wg)[((size_t)c * L + n) * 9 + (st % 9)] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (!nv) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (mm < M) dstp[(size_t)mm * L + n] = acc[r];
     }
 }
 // dA_w[k,j] = sum_{b,l} dstp[b,k,l]*st[b,j,l]; dA_b[k] = sum_{b,l} dstp[b,k,l]; one workgroup per output
@@ -109,10 +171,13 @@ extern "C" int dasr_dynk_bwd(const float* dD, const float* st, const float* stp,
     DASR_CHECK_PTR(dst); DASR_CHECK_PTR(dstp);
     DASR_CHECK_SHAPE(B > 0 && K > 0 && L > 0 && C > 0);
     size_t nW = (size_t)2 * C * L * 9, nS = (size_t)B * K * L;
-    DASR_LAUNCH(k_dynk_dW, dim3(dasr_ew_grid(nW)), dim3(256), 0, stream, dD, stp, dWg, dWb, B, K, L, C, nW);
-    hipError_t e = hipMemsetAsync(dstp, 0, sizeof(float) * nS, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    DASR_LAUNCH(k_dynk_dstp, dim3(dasr_ew_grid(nS), 18), dim3(256), 0, stream, dD, Wg, Wb, dstp, K, L, C, nS);
+    (void)nW;
+    {
+        int tiles = ((18 * C + 31) / 32) * ((L + 31) / 32);
+        DASR_LAUNCH(k_dynk_dW_mfma, dim3((tiles + 3) / 4), dim3(256), 0, stream, dD, stp, dWg, dWb, B, K, L, C);
+        tiles = ((B * K + 31) / 32) * ((L + 31) / 32);
+        DASR_LAUNCH(k_dynk_dstp_mfma, dim3((tiles + 3) / 4), dim3(256), 0, stream, dD, Wg, Wb, dstp, B, K, L, C);
+    }
     DASR_LAUNCH(k_dynk_dA, dim3(K * K + K), dim3(256), 0, stream, dstp, st, dA_w, dA_b, B, K, L);
     DASR_LAUNCH(k_dynk_dst, dim3(dasr_ew_grid(nS)), dim3(256), 0, stream, dstp, A_w, dst, K, L, nS);
     DASR_RETURN_LAUNCH_STATUS();
