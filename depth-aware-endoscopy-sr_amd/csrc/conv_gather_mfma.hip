@@ -68,7 +68,6 @@ __device__ __forceinline__ bool gather_pixel(int B, int Ho, int Wo, int stride, 
 template <int NT>
 __global__ void __launch_bounds__(256) k_conv_gather_mfma(GatherArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-    const size_t M = (size_t)a.B * a.Ho * a.Wo;
     const size_t m = ((size_t)blockIdx.x * 4 + wv) * 32 + li;      // this lane's output pixel (A row)
     const int n0 = blockIdx.y * 32 * NT;
     int ox = 0, oy = 0, b = 0;
@@ -92,12 +91,8 @@ __global__ void __launch_bounds__(256) k_conv_gather_mfma(GatherArgs a) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int nn = n0 + 32 * n + li;
-                    if (a.wt == 0) {
-                        const float* wp = a.w + ((size_t)tap * a.Kd + c0 + 4 * lh) * a.Nd + nn;
-                        Bf[n] = make_float4(wp[0], wp[a.Nd], wp[2 * (size_t)a.Nd], wp[3 * (size_t)a.Nd]);
-                    } else {
-                        Bf[n] = *(const float4*)(a.w + ((size_t)tap * a.Nd + nn) * a.Kd + c0 + 4 * lh);
-                    }
+                    // [tap][n][k] with k contiguous: the transposed half for the forward, the HWIO half for dgrad
+                    Bf[n] = *(const float4*)(a.w + ((size_t)tap * a.Nd + nn) * a.Kd + c0 + 4 * lh);
                 }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
@@ -159,15 +154,15 @@ __global__ void __launch_bounds__(256) k_conv_gather_wgrad_mfma(GatherWgradArgs 
     for (size_t mb = m0; mb < m1; mb += 2) {
         const size_t m = mb + lh;
         float av = 0.f, b0 = 0.f, b1 = 0.f;
-        int ox, oy, b, iy, ix;
-        const bool ok = m < m1 && gather_pixel(a.B, a.Ho, a.Wo, a.stride, a.transposed, m, b, oy, ox) &&
-                        gather_src(ga, oy, ox, kh, kw, iy, ix);
-        if (!__any(ok)) continue;                           // this tap reads no input pixel for these two outputs
-        if (ok) {
-            av = a.x[(((size_t)b * a.H + iy) * a.W + ix) * a.Cin + 32 * ct + li];
-            const float* dp = a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + 64 * cp + li;
-            b0 = dp[0];
-            b1 = dp[32];
+        if (m < m1) {
+            const int ox = (int)(m % a.Wo), oy = (int)((m / a.Wo) % a.Ho), b = (int)(m / ((size_t)a.Wo * a.Ho));
+            int iy, ix;
+            if (gather_src(ga, oy, ox, kh, kw, iy, ix)) {
+                av = a.x[(((size_t)b * a.H + iy) * a.W + ix) * a.Cin + 32 * ct + li];
+                const float* dp = a.dy + m * a.Cout + 64 * cp + li;
+                b0 = dp[0];
+                b1 = dp[32];
+            }
         }
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
@@ -199,8 +194,8 @@ static int launch_gather(GatherArgs& a, void* stream) {
 }
 int conv_gather_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act,
                     void* stream) {
-    GatherArgs a{x, w, bias, y, g.B, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout, g.KH, g.KW, g.stride, g.pad,
-                 g.transposed ? 1 : 0, 0, act, 0};
+    GatherArgs a{x, w + (size_t)g.KH * g.KW * g.Cin * g.Cout, bias, y, g.B, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout, g.KH,
+                 g.KW, g.stride, g.pad, g.transposed ? 1 : 0, 0, act, 0};
     return launch_gather(a, stream);
 }
 int conv_gather_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream) {

@@ -29,7 +29,7 @@
 
 struct ConvMfmaArgs {
     const float* x;         // [B,H,W,Cin]
-    const float* w;         // WMODE 0: HWIO [9][Cin][Cout];  WMODE 1: HWIO of the forward conv, [9][Cout][Cin]
+    const float* w;         // packed kernel of the FORWARD conv: HWIO then per-tap transpose (dasr_weight_pack_fwd)
     const float* bias;      // [Cout] or null
     const float* residual;  // [B,H,W,Cout] or null
     float* y;
@@ -57,34 +57,62 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    for (int c0 = 0; c0 < a.Cin; c0 += CM_CK) {
-        __syncthreads();
-        // ---- stage the input halo tile: one float4 (4 channels) per thread-iteration
-        for (int idx = tid; idx < CM_HALO_H * CM_HALO_W * 4; idx += 256) {
-            int pix = idx >> 2, q4 = idx & 3;
-            int gy = y0 + pix / CM_HALO_W - 1, gx = x0 + pix % CM_HALO_W - 1;
+    // Software pipeline over the 16-channel chunks: the global loads of chunk c+1 are issued into registers before
+    // the MFMA work of chunk c starts and are written to LDS after it (split "issue early / write late" staging),
+    // so their latency hides under this workgroup's own matrix work instead of relying on the co-resident one.
+    constexpr int NIN = (CM_HALO_H * CM_HALO_W * 4 + 255) / 256;
+    constexpr int NWT = (9 * NTILE * 4 + 255) / 256;
+    float4 pin[NIN], pwt[NWT];
+    const float* wsrc = WMODE == 0 ? a.w + (size_t)9 * a.Cin * a.Cout : a.w;
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            const int idx = tid + 256 * u;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
-            *(float4*)(sIn + pix * CM_CKP + 4 * q4) = v;
-        }
-        // ---- stage the weight slice as [tap][n][k]
-        if (WMODE == 0) {
-            // source HWIO [tap][ci][co]: co contiguous -> transpose into [n = co][k = ci]
-            for (int idx = tid; idx < 9 * CM_CK * NTILE; idx += 256) {
-                int nl = idx % NTILE, kl = (idx / NTILE) % CM_CK, tap = idx / (NTILE * CM_CK);
-                sW[(tap * NTILE + nl) * CM_CKP + kl] = a.w[((size_t)tap * a.Cin + c0 + kl) * a.Cout + n0 + nl];
+            if (idx < CM_HALO_H * CM_HALO_W * 4) {
+                const int pix = idx >> 2, q4 = idx & 3;
+                const int gy = y0 + pix / CM_HALO_W - 1, gx = x0 + pix % CM_HALO_W - 1;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
             }
-        } else {
-            // dgrad: this kernel's (Cin, Cout) = the forward conv's (Cout_f, Cin_f); source HWIO_f [tap][n][k]
-            // with k contiguous; taps flipped (tap' = 8 - tap)
-            for (int idx = tid; idx < 9 * NTILE * 4; idx += 256) {
-                int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
-                float4 v = *(const float4*)(a.w + ((size_t)(8 - tap) * a.Cout + n0 + nl) * a.Cin + c0 + 4 * q4);
-                *(float4*)(sW + (tap * NTILE + nl) * CM_CKP + 4 * q4) = v;
+            pin[u] = v;
+        }
+        // weight slice as [tap][n][k]: both modes read a [tap][n][k]-ordered source with k contiguous
+        //   forward: second half of the packed kernel, [tap][co][ci]
+        //   dgrad  : first half (HWIO of the forward conv = [tap][n = ci_f][k = co_f]) with the taps flipped
+#pragma unroll
+        for (int u = 0; u < NWT; ++u) {
+            const int idx = tid + 256 * u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < 9 * NTILE * 4) {
+                const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
+                const int tsrc = WMODE == 0 ? tap : 8 - tap;
+                v = *(const float4*)(wsrc + ((size_t)tsrc * a.Cout + n0 + nl) * a.Cin + c0 + 4 * q4);
+            }
+            pwt[u] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < CM_HALO_H * CM_HALO_W * 4) *(float4*)(sIn + (idx >> 2) * CM_CKP + 4 * (idx & 3)) = pin[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NWT; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < 9 * NTILE * 4) {
+                const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
+                *(float4*)(sW + (tap * NTILE + nl) * CM_CKP + 4 * q4) = pwt[u];
             }
         }
+    };
+    prefetch(0);
+    for (int c0 = 0; c0 < a.Cin; c0 += CM_CK) {
+        __syncthreads();                       // every wave is done reading the previous chunk
+        commit();
         __syncthreads();
+        if (c0 + CM_CK < a.Cin) prefetch(c0 + CM_CK);
         // ---- 9 taps x 16 channels = 72 K=2 steps per accumulator
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {

@@ -101,33 +101,19 @@ __global__ void __launch_bounds__(256) k_dynk_dW_mfma(const float* __restrict__ 
         (st2 >= 9 ? dWb : dWg)[((size_t)c2 * L + n) * 9 + (st2 % 9)] = acc[r];
     }
 }
-// dstp[b,k,l] = sum_{(st,c)} dD[b,st,k,c] * W_s[c,l,tap]      M = (b,k), N = l, K = (st,c)
-__global__ void __launch_bounds__(256) k_dynk_dstp_mfma(const float* __restrict__ dD, const float* __restrict__ Wg,
-                                                        const float* __restrict__ Wb, float* __restrict__ dstp, int B,
-                                                        int K, int L, int C) {
-    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-    const int M = B * K, N = L, KK = 18 * C;
-    const int tiles_n = (N + 31) / 32;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= ((M + 31) / 32) * tiles_n) return;
-    const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
-    const int m = m0 + li, n = n0 + li;
-    const bool mv = m < M, nv = n < N;
-    const int b = mv ? m / K : 0, k = mv ? m % K : 0;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int kk = lh; kk < KK; kk += 2) {          // 18*C is even
-        const int st = kk / C, c = kk % C;
-        const float av = mv ? dD[(((size_t)b * 18 + st) * K + k) * C + c] : 0.f;
-        const float bv = nv ? (st >= 9 ? Wb : Wg)[((size_t)c * L + n) * 9 + (st % 9)] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-    if (!nv) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (mm < M) dstp[(size_t)mm * L + n] = acc[r];
+// dstp[b,k,l] = sum_{s,tap,c} dD[b,s,tap,k,c] * W_s[c,l,tap]; blockIdx.y = (s,tap) slice, partial sums are
+// added with float atomics into the zeroed dstp (18 adds per element)
+__global__ void k_dynk_dstp(const float* __restrict__ dD, const float* __restrict__ Wg, const float* __restrict__ Wb,
+                            float* __restrict__ dstp, int K, int L, int C, size_t n) {
+    const int st = blockIdx.y, s = st / 9, tap = st % 9;
+    const float* Wp = s ? Wb : Wg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int l = (int)(i % L), k = (int)((i / L) % K);
+        size_t b = i / ((size_t)L * K);
+        const float* dp = dD + ((b * 18 + st) * K + k) * C;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(dp[c], Wp[((size_t)c * L + l) * 9 + tap], acc);
+        atomicAdd(&dstp[i], acc);
     }
 }
 // dA_w[k,j] = sum_{b,l} dstp[b,k,l]*st[b,j,l]; dA_b[k] = sum_{b,l} dstp[b,k,l]; one workgroup per output
@@ -175,9 +161,10 @@ extern "C" int dasr_dynk_bwd(const float* dD, const float* st, const float* stp,
     {
         int tiles = ((18 * C + 31) / 32) * ((L + 31) / 32);
         DASR_LAUNCH(k_dynk_dW_mfma, dim3((tiles + 3) / 4), dim3(256), 0, stream, dD, stp, dWg, dWb, B, K, L, C);
-        tiles = ((B * K + 31) / 32) * ((L + 31) / 32);
-        DASR_LAUNCH(k_dynk_dstp_mfma, dim3((tiles + 3) / 4), dim3(256), 0, stream, dD, Wg, Wb, dstp, B, K, L, C);
     }
+    hipError_t e = hipMemsetAsync(dstp, 0, sizeof(float) * nS, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    DASR_LAUNCH(k_dynk_dstp, dim3(dasr_ew_grid(nS), 18), dim3(256), 0, stream, dD, Wg, Wb, dstp, K, L, C, nS);
     DASR_LAUNCH(k_dynk_dA, dim3(K * K + K), dim3(256), 0, stream, dstp, st, dA_w, dA_b, B, K, L);
     DASR_LAUNCH(k_dynk_dst, dim3(dasr_ew_grid(nS)), dim3(256), 0, stream, dstp, A_w, dst, K, L, nS);
     DASR_RETURN_LAUNCH_STATUS();

@@ -39,7 +39,15 @@ __global__ void __launch_bounds__(256) k_weight_pack_fwd(const float* __restrict
         if (threadIdx.x == 0 && inv_norm) inv_norm[n] = inv;
         scale = g[n] * inv;
     }
-    for (int r = threadIdx.x; r < R; r += 256) w[hwio_index(n, r, ldo, o_off, I, KK, transposed)] = vn[r] * scale;
+    // second half of the packed buffer: the same kernel with each tap transposed, [tap][ldo][I]
+    float* wT = w + (size_t)KK * I * ldo;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float val = vn[r] * scale;
+        w[hwio_index(n, r, ldo, o_off, I, KK, transposed)] = val;
+        int a = r / KK, t = r % KK;
+        int o = transposed ? a : n, i = transposed ? n : a;
+        wT[((size_t)t * ldo + o_off + o) * I + i] = val;
+    }
 }
 
 // dv = (g/||v||) * (dw - v * <dw,v>/||v||^2) ; dg = <dw,v>/||v||

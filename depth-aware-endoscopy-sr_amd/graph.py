@@ -39,7 +39,7 @@ def pack_pair(tape, va, vb):
     """Two plain OIHW kernels with equal Cin side by side along Cout (mlp_gamma_o | mlp_beta_o)."""
     Oa, I, KH, KW = va.data.shape
     Ob = vb.data.shape[0]
-    w = ops.empty((KH, KW, I, Oa + Ob), va.data)
+    w = ops.empty((2, KH, KW, I, Oa + Ob), va.data)
     ops.weight_pack(va.data, None, False, out=w, o_off=0)
     ops.weight_pack(vb.data, None, False, out=w, o_off=Oa)
     out = Var(w, va.requires_grad or vb.requires_grad)
@@ -82,7 +82,8 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
     needs = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad) or \
         (residual is not None and residual.requires_grad)
     out = Var(y, needs)
-    KH, KW, Cin, Cout = w.data.shape
+    KH, KW, Cin, Cout = w.data.shape[1:]
+    wshape = (KH, KW, Cin, Cout)
     B, H, W_, _ = x.data.shape
     Ho, Wo = ops.conv_out_hw(H, W_, KH, KW, stride, pad, transposed)
 
@@ -93,7 +94,7 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
         out.grad = None
         if not x.requires_grad and residual is None and ps_r == 1 and act != ops.ACT_NONE:
             # leaf layer (the depth-map branch): activation backward fused into the weight gradient
-            dw, db = ops.conv2d_wgrad_act(x.data, dy, y, w.data.shape, act, stride, pad, transposed,
+            dw, db = ops.conv2d_wgrad_act(x.data, dy, y, wshape, act, stride, pad, transposed,
                                           want_bias=bias is not None)
             accum(w, dw)
             if bias is not None:
@@ -104,7 +105,7 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
         else:
             dconv = dy
         if w.requires_grad or (bias is not None and bias.requires_grad):
-            dw, db = ops.conv2d_wgrad(x.data, dconv, w.data.shape, stride, pad, transposed,
+            dw, db = ops.conv2d_wgrad(x.data, dconv, wshape, stride, pad, transposed,
                                       want_bias=bias is not None)
             accum(w, dw)
             if bias is not None:

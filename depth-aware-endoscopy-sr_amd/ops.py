@@ -93,8 +93,8 @@ def weight_pack(v, g, transposed=False, out=None, o_off=0):
     else:
         O, I, KH, KW = v.shape
     if out is None:
-        out = empty((KH, KW, I, O), v)
-    ldo = out.shape[3]
+        out = empty((2, KH, KW, I, O), v)          # [0]: HWIO, [1]: memory holds the per-tap transpose [KH,KW,O,I]
+    ldo = out.shape[4]
     inv = empty((I if transposed else O,), v) if g is not None else None
     _call("dasr_weight_pack_fwd", _p(v), _p(g, True), _p(out), _p(inv, True), O, I, KH, KW, int(transposed), ldo,
           int(o_off))
@@ -108,6 +108,7 @@ def weight_pack_bwd(dw, v, g, inv, transposed=False, o_off=0):
         O, I, KH, KW = v.shape
     dv = torch.empty_like(v)
     dg = torch.empty_like(g) if g is not None else None
+    assert dw.dim() == 4, "weight gradients are plain HWIO"
     _call("dasr_weight_pack_bwd", _p(dw), _p(v), _p(g, True), _p(inv, True), _p(dv), _p(dg, True), O, I, KH, KW,
           int(transposed), dw.shape[3], int(o_off))
     return dv, dg
@@ -120,9 +121,25 @@ def conv_out_hw(H, W, KH, KW, stride, pad, transposed):
     return (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
 
 
+def pack_hwio(w4):
+    """Packed kernel (HWIO + per-tap transpose) from a plain HWIO tensor - for tests and micro-benchmarks; the
+    product path gets packed kernels from weight_pack (dasr_weight_pack_fwd)."""
+    KH, KW, I, O = w4.shape
+    out = torch.empty((2, KH, KW, I, O), dtype=w4.dtype, device=w4.device)
+    out[0].copy_(w4)
+    out[1].view(KH, KW, O, I).copy_(w4.permute(0, 1, 3, 2))
+    return out
+
+
+def _wdims(w):
+    if w.dim() != 5 or w.shape[0] != 2:
+        raise ValueError("dasr_amd: convolution kernels must be packed (ops.weight_pack / ops.pack_hwio)")
+    return tuple(w.shape[1:])
+
+
 def conv2d_fwd(x, w, bias=None, residual=None, stride=1, pad=1, transposed=False, act=ACT_NONE, ps_r=1):
     B, H, W, Cin = x.shape
-    KH, KW, wi, Cout = w.shape
+    KH, KW, wi, Cout = _wdims(w)
     assert wi == Cin, (w.shape, x.shape)
     Ho, Wo = conv_out_hw(H, W, KH, KW, stride, pad, transposed)
     if ps_r > 1:
@@ -143,7 +160,7 @@ def conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r):
 
 def conv2d_dgrad(dconv, w, x_shape, stride=1, pad=1, transposed=False, out=None):
     B, H, W, Cin = x_shape
-    KH, KW, _, Cout = w.shape
+    KH, KW, _, Cout = _wdims(w)
     _, Ho, Wo, _ = dconv.shape
     acc = out is not None
     if out is None:

@@ -14,7 +14,10 @@
  *   - activations are NHWC  [B][H][W][C]  (C fastest); the NCHW tensors of the reference
  *     API (input image, depth masks, output image) are converted at the edge by
  *     dasr_nchw_to_nhwc / dasr_clamp_to_nchw or read in place (masks).
- *   - convolution kernels are packed "HWIO"  [KH][KW][Cin][Cout]  by dasr_weight_pack_fwd.
+ *   - convolution kernels are packed by dasr_weight_pack_fwd into 2*KH*KW*Cin*Cout floats: "HWIO"
+ *     [KH][KW][Cin][Cout] followed by the per-tap transpose [KH][KW][Cout][Cin] (so that forward and
+ *     data-gradient kernels both stream their K axis contiguously).  Every `w_hwio` argument of the
+ *     convolution entry points is such a packed buffer; weight GRADIENTS (dw_hwio) are plain HWIO.
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, never
  *     synchronise, never allocate, never throw.  Re-entrant: no global mutable state.
  *   - return value: 0 on success, a DASR_E_* code (<0) for bad arguments, or a positive
@@ -64,7 +67,7 @@ int dasr_resize_nearest_nchw(const float* src, float* dst, int BC, int h, int w,
  *   w = g * v / ||v||  with the norm over all dims but 0.
  * v is [O][I][KH][KW] for Conv2d, [I][O][KH][KW] for ConvTranspose2d (transposed=1: dim 0 is the
  * IN-channel axis, encoder.layer4).  g == NULL packs a plain weight (no normalisation).
- * Output: w_hwio [KH][KW][I][ldo], written at output-channel offset o_off (ldo >= o_off + O lets several
+ * Output: w_hwio = [KH][KW][I][ldo] then [KH][KW][ldo][I] (2*KH*KW*I*ldo floats), written at output-channel offset o_off (ldo >= o_off + O lets several
  * modules share one packed kernel: mlp_gamma_o | mlp_beta_o, normalization.py:41-42, run as one 2C->2C conv);
  * inv_norm [O or I] (1/||v||, kept for the backward; may be NULL when g is).
  */

@@ -173,7 +173,7 @@ def check_pixel_shuffle_bit_exact(device):
         B, Crr, H, W = (int(v) for v in g["src_shape"])
         src = torch.arange(B * Crr * H * W, dtype=torch.float32).reshape(B, Crr, H, W)
         # identity 1x1 convolution (w = I) routes the input through the conv epilogue unchanged
-        w = torch.eye(Crr).reshape(1, 1, Crr, Crr).contiguous().to(device)
+        w = ops.pack_hwio(torch.eye(Crr).reshape(1, 1, Crr, Crr).contiguous().to(device))
         y = ops.conv2d_fwd(nhwc(src).to(device), w, None, None, stride=1, pad=0, act=ops.ACT_NONE, ps_r=r)
         out = nchw(y).cpu().numpy().astype(np.int32)
         assert np.array_equal(out, g["out"]), r

@@ -66,24 +66,24 @@ def main():
                   (256, 320, 64, 32), (256, 320, 32, 32), (256, 320, 32, 128), (512, 640, 32, 32), (512, 640, 32, 128)]
         for (h, w, ci, co) in shapes:
             x = torch.randn(B, h, w, ci, device=dev)
-            wt = torch.randn(3, 3, ci, co, device=dev) * 0.05
+            wt = ops.pack_hwio(torch.randn(3, 3, ci, co, device=dev) * 0.05)
             bias = torch.randn(co, device=dev)
             y = ops.conv2d_fwd(x, wt, bias)
             fl = 2.0 * 9 * ci * co * B * h * w
             us = timeit(lambda: ops.conv2d_fwd(x, wt, bias), a.iters)
             us_d = timeit(lambda: ops.conv2d_dgrad(y, wt, x.shape), a.iters)
-            us_w = timeit(lambda: ops.conv2d_wgrad(x, y, wt.shape), a.iters)
+            us_w = timeit(lambda: ops.conv2d_wgrad(x, y, tuple(wt.shape[1:])), a.iters)
             print("conv3x3 %3dx%3d %3d->%3d  fwd %8.1f us %6.1f TF | dgrad %8.1f us %6.1f TF | wgrad(+bias) %8.1f us %6.1f TF"
                   % (h, w, ci, co, us, fl / us / 1e6, us_d, fl / us_d / 1e6, us_w, fl / us_w / 1e6))
             del x, y
         x = torch.randn(B, 1024, 1280, 32, device=dev)
-        wt = torch.randn(9, 9, 32, 3, device=dev) * 0.02
+        wt = ops.pack_hwio(torch.randn(9, 9, 32, 3, device=dev) * 0.02)
         bias = torch.randn(3, device=dev)
         y = ops.conv2d_fwd(x, wt, bias, pad=4)
         fl = 2.0 * 81 * 32 * 3 * B * 1024 * 1280
         us = timeit(lambda: ops.conv2d_fwd(x, wt, bias, pad=4), a.iters)
         us_d = timeit(lambda: ops.conv2d_dgrad(y, wt, x.shape, pad=4), a.iters)
-        us_w = timeit(lambda: ops.conv2d_wgrad(x, y, wt.shape, pad=4), a.iters)
+        us_w = timeit(lambda: ops.conv2d_wgrad(x, y, tuple(wt.shape[1:]), pad=4), a.iters)
         print("conv9x9 1024x1280 32->3   fwd %8.1f us %6.1f TF | dgrad %8.1f us %6.1f TF | wgrad(+bias) %8.1f us %6.1f TF"
               % (us, fl / us / 1e6, us_d, fl / us_d / 1e6, us_w, fl / us_w / 1e6))
 
