@@ -15,8 +15,8 @@
 
 #define C9_TH 8           // tile rows
 #define C9_TQ 64          // tile columns (forward: includes the 8-column halo; 56 outputs per tile)
-#define C9_CK 16
-#define C9_CKP 20
+#define C9_CK 8            // channels per K chunk: 63 KB of LDS per workgroup -> two workgroups per CU
+#define C9_CKP 12          // LDS pixel stride in floats (conflict-free ds_read_b128 at a 48-byte stride)
 #define C9_PST 28         // P row stride (27 used)
 #define C9_DYW ((C9_TQ + 8) * 3 + 8)   // dy tile row stride in floats: 72 px * 3 ch + pad
 
@@ -49,8 +49,8 @@ __global__ void __launch_bounds__(256) k_conv9x9_fwd_mfma(Conv9Args a) {
 
     for (int c0 = 0; c0 < a.Cin; c0 += C9_CK) {
         __syncthreads();
-        for (int idx = tid; idx < (C9_TH + 8) * C9_TQ * 4; idx += 256) {
-            int q4 = idx & 3, pix = idx >> 2;
+        for (int idx = tid; idx < (C9_TH + 8) * C9_TQ * (C9_CK / 4); idx += 256) {
+            int q4 = idx % (C9_CK / 4), pix = idx / (C9_CK / 4);
             int gy = y0 - 4 + pix / C9_TQ, gx = x0 - 4 + pix % C9_TQ;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
@@ -67,10 +67,10 @@ __global__ void __launch_bounds__(256) k_conv9x9_fwd_mfma(Conv9Args a) {
             sW[(kh * 32 + n) * C9_CKP + k] = v;
         }
         __syncthreads();
-#pragma unroll 1
+#pragma unroll 3
         for (int kh = 0; kh < 9; ++kh) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < C9_CK / 8; ++q) {
                 const float4 Bf = *(const float4*)(sW + (kh * 32 + li) * C9_CKP + 8 * q + 4 * lh);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {

@@ -211,8 +211,10 @@ bool conv_mfma_dgrad_supported(const ConvGeom& g) {
 // pixel of the pair).  A fragment: lane i reads channel ci0+i of pixel (p + off(tap)) -> 32 consecutive
 // floats per half-wave (conflict-free ds_read_b32); B fragment likewise from the dconv tile.  Each strip
 // writes its partial dW as a slab; k_wgrad_reduce sums the slabs in a fixed order (bitwise reproducible).
-#define WG_TH 2
 #define WG_TW 32
+// tile rows per (MT, NTW): fewer channels per workgroup -> less LDS per pixel -> taller tiles, so that the fixed
+// per-tile cost (two barriers, staging latency) is amortised over the same amount of MFMA work
+__host__ __device__ constexpr int wg_th(int MT, int NTW) { return MT * NTW == 4 ? 2 : (MT * NTW == 2 ? 4 : 8); }
 
 struct WgradArgs {
     const float* x;      // [B,H,W,Cin]
@@ -227,6 +229,7 @@ template <int MT, int NTW>
 __global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
     DASR_DYN_SMEM(smem);
     constexpr int CIG = 32 * MT, COG = 32 * NTW;
+    constexpr int WG_TH = wg_th(MT, NTW);
     constexpr int G = 4 / (MT * NTW);           // wave groups sharing one (mt, nt) pair, splitting the taps
     constexpr int NACC = (9 + G - 1) / G;
     float* sX = (float*)smem;                                   // [(TH+2)*(TW+2)][CIG]
@@ -364,7 +367,8 @@ static void wgrad_plan(const ConvGeom& g, int& MT, int& NTW, int& groups, int& n
     MT = (g.Cin % 64) == 0 ? 2 : 1;
     NTW = (g.Cout % 64) == 0 ? 2 : 1;
     groups = (g.Cin / (32 * MT)) * (g.Cout / (32 * NTW));
-    ntiles = g.B * ((g.H + WG_TH - 1) / WG_TH) * ((g.W + WG_TW - 1) / WG_TW);
+    const int th = wg_th(MT, NTW);
+    ntiles = g.B * ((g.H + th - 1) / th) * ((g.W + WG_TW - 1) / WG_TW);
     P = 512 / groups;
     if (P < 1) P = 1;
     if (P > ntiles) P = ntiles;
@@ -383,7 +387,8 @@ int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float
         if (e != hipSuccess) return (int)e;
     }
     WgradArgs a{x, dconv, (float*)workspace, dbias, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
-    size_t lds = sizeof(float) * (size_t)((WG_TH + 2) * (WG_TW + 2) * 32 * MT + WG_TH * WG_TW * 32 * NTW);
+    const int th = wg_th(MT, NTW);
+    size_t lds = sizeof(float) * (size_t)((th + 2) * (WG_TW + 2) * 32 * MT + th * WG_TW * 32 * NTW);
     dim3 grid(groups, P);
     if (MT == 2 && NTW == 2) {
         DASR_LAUNCH((k_conv3x3_wgrad_mfma<2, 2>), grid, dim3(256), lds, stream, a);
