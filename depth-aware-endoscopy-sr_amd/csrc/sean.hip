@@ -299,6 +299,10 @@ extern "C" int dasr_mask_compress(const float* mask, unsigned char* region, int*
     DASR_RETURN_LAUNCH_STATUS();
 }
 
+__device__ __forceinline__ float4 ld_nt4(const float* p) {
+    f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // Stage D[b] (channel slice c0..c0+63) as [18][K+1][64] with a zero row K ("no region": outside the image
@@ -352,65 +356,87 @@ __global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float
                                                          const float* __restrict__ alpha_g,
                                                          const float* __restrict__ alpha_b,
                                                          const float* __restrict__ residual, float* __restrict__ out,
-                                                         int relu, float eps) {
+                                                         int relu, float eps, int tiles_per_wg) {
     if (flag && *flag != 0) return;   // masks are not one-hot: the general kernel does the work
     DASR_DYN_SMEM(smem);
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                                  // [18][K+1][64]
     unsigned char* sR = (unsigned char*)(sD + 18 * K1 * 64);   // [(TH+2)*(TW+2)]
-    const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
-    const int x0 = (blockIdx.x % tiles_x) * SF_TW, y0 = (blockIdx.x / tiles_x) * SF_TH;
-    const int b = blockIdx.y, c0 = blockIdx.z * 64;
-    sean_stage_D(g, D, sD, b, c0);
-    sean_stage_R(g, region, sR, b, y0, x0, SF_TH);
-    __syncthreads();
+    const int tiles_x = (g.W + SF_TW - 1) / SF_TW, tiles_y = (g.H + SF_TH - 1) / SF_TH;
+    const int tiles_per_sample = tiles_x * tiles_y;
+    const int c0 = blockIdx.y * 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cq = lane & 15, ps = lane >> 4;
     const int c = c0 + 4 * cq;
-    if (c >= g.C) return;
+    const bool live = c < g.C;
     const float a_g = alpha_g[0], a_b = alpha_b[0];
-    const float4 mu = *(const float4*)(mean + (size_t)b * g.C + c);
-    const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
-    const float4 sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
-                                  dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
-    const float4 bg = *(const float4*)(bias_g + c), bb = *(const float4*)(bias_b + c);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-    for (int ly = wv; ly < SF_TH; ly += 4) {
-        const int y = y0 + ly;
-        if (y >= g.H) break;
-#pragma unroll 1
-        for (int hx = 0; hx < SF_TW; hx += 16) {
-            float4 tv[4], g2[4], b2[4], rv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int x = x0 + hx + 4 * u + ps;
-                tv[u] = zero4; g2[u] = zero4; b2[u] = zero4; rv[u] = zero4;
-                if (x < g.W) {
-                    const size_t p = ((size_t)b * g.H + y) * g.W + x;
-                    tv[u] = *(const float4*)(t + p * g.C + c);
-                    g2[u] = *(const float4*)(gb2 + p * 2 * g.C + c);
-                    b2[u] = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
-                    if (residual) rv[u] = *(const float4*)(residual + p * g.C + c);
-                }
+    float4 bg = zero4, bb = zero4;
+    if (live) {
+        bg = *(const float4*)(bias_g + c);
+        bb = *(const float4*)(bias_b + c);
+    }
+    // Persistent workgroup: a contiguous chunk of (sample, tile) pairs; D[b] is restaged only when the sample
+    // changes, so its 50 KB L2->LDS copy is paid about once per workgroup instead of once per 256-pixel tile.
+    const int first = blockIdx.x * tiles_per_wg;
+    int last = first + tiles_per_wg;
+    if (last > g.B * tiles_per_sample) last = g.B * tiles_per_sample;
+    int cur_b = -1;
+    float4 mu = zero4, sc = zero4;
+    for (int tt = first; tt < last; ++tt) {
+        const int b = tt / tiles_per_sample, tile = tt % tiles_per_sample;
+        const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SF_TH;
+        __syncthreads();                                   // previous tile is done with sR (and sD)
+        if (b != cur_b) {
+            sean_stage_D(g, D, sD, b, c0);
+            cur_b = b;
+            if (live) {
+                mu = *(const float4*)(mean + (size_t)b * g.C + c);
+                const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
+                sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
+                                 dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
             }
+        }
+        sean_stage_R(g, region, sR, b, y0, x0, SF_TH);
+        __syncthreads();
+        if (!live) continue;
+#pragma unroll 1
+        for (int ly = wv; ly < SF_TH; ly += 4) {
+            const int y = y0 + ly;
+            if (y >= g.H) break;
+#pragma unroll 1
+            for (int hx = 0; hx < SF_TW; hx += 16) {
+                float4 tv[4], g2[4], b2[4], rv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int lx = hx + 4 * u + ps, x = x0 + lx;
-                if (x >= g.W) continue;
-                const size_t p = ((size_t)b * g.H + y) * g.W + x;
-                float4 g1, b1;
-                sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
-                float4 o;
-                o.x = (tv[u].x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * g2[u].x) + a_b * b1.x + (1.f - a_b) * b2[u].x + rv[u].x;
-                o.y = (tv[u].y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * g2[u].y) + a_b * b1.y + (1.f - a_b) * b2[u].y + rv[u].y;
-                o.z = (tv[u].z - mu.z) * sc.z * (1.f + a_g * g1.z + (1.f - a_g) * g2[u].z) + a_b * b1.z + (1.f - a_b) * b2[u].z + rv[u].z;
-                o.w = (tv[u].w - mu.w) * sc.w * (1.f + a_g * g1.w + (1.f - a_g) * g2[u].w) + a_b * b1.w + (1.f - a_b) * b2[u].w + rv[u].w;
-                if (relu) {
-                    o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
-                    o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+                for (int u = 0; u < 4; ++u) {
+                    const int x = x0 + hx + 4 * u + ps;
+                    tv[u] = zero4; g2[u] = zero4; b2[u] = zero4; rv[u] = zero4;
+                    if (x < g.W) {
+                        const size_t p = ((size_t)b * g.H + y) * g.W + x;
+                        tv[u] = ld_nt4(t + p * g.C + c);          // streamed once: keep it out of the way of D / halos
+                        g2[u] = ld_nt4(gb2 + p * 2 * g.C + c);
+                        b2[u] = ld_nt4(gb2 + p * 2 * g.C + g.C + c);
+                        if (residual) rv[u] = *(const float4*)(residual + p * g.C + c);
+                    }
                 }
-                *(float4*)(out + p * g.C + c) = o;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int lx = hx + 4 * u + ps, x = x0 + lx;
+                    if (x >= g.W) continue;
+                    const size_t p = ((size_t)b * g.H + y) * g.W + x;
+                    float4 g1, b1;
+                    sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
+                    float4 o;
+                    o.x = (tv[u].x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * g2[u].x) + a_b * b1.x + (1.f - a_b) * b2[u].x + rv[u].x;
+                    o.y = (tv[u].y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * g2[u].y) + a_b * b1.y + (1.f - a_b) * b2[u].y + rv[u].y;
+                    o.z = (tv[u].z - mu.z) * sc.z * (1.f + a_g * g1.z + (1.f - a_g) * g2[u].z) + a_b * b1.z + (1.f - a_b) * b2[u].z + rv[u].z;
+                    o.w = (tv[u].w - mu.w) * sc.w * (1.f + a_g * g1.w + (1.f - a_g) * g2[u].w) + a_b * b1.w + (1.f - a_b) * b2[u].w + rv[u].w;
+                    if (relu) {
+                        o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                        o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+                    }
+                    *(float4*)(out + p * g.C + c) = o;
+                }
             }
         }
     }
@@ -640,10 +666,13 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
     const bool fast = region != nullptr && (C % 4) == 0;
     const bool fast_only = fast && onehot_flag == nullptr;   // the caller vouches for one-hot masks
     if (fast) {
-        int tiles = ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
+        int tiles = B * ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
+        int slices = (int)dasr_cdiv(C, 64);
+        int per = (tiles * slices + 767) / 768;            // 256 CUs x 3 resident workgroups (51 KB of LDS each)
+        if (per < 1) per = 1;
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
-        DASR_LAUNCH(k_sean_fwd_onehot, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2,
-                    region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps);
+        DASR_LAUNCH(k_sean_fwd_onehot, dim3((tiles + per - 1) / per, slices), dim3(256), lds, stream, g, t, mean, var,
+                    gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps, per);
     }
     if (!fast_only) {
         int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);

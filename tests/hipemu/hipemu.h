@@ -56,6 +56,8 @@ void* wave_buf();  // >= 64 * 64 bytes of per-wave exchange scratch
 extern char* dyn_smem;
 }  // namespace hipemu
 
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 static inline void __syncthreads() { hipemu::block_barrier(); }
 
 template <class T>
