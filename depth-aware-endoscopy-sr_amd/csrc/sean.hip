@@ -400,44 +400,55 @@ __global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float
         sean_stage_R(g, region, sR, b, y0, x0, SF_TH);
         __syncthreads();
         if (!live) continue;
-#pragma unroll 1
-        for (int ly = wv; ly < SF_TH; ly += 4) {
-            const int y = y0 + ly;
-            if (y >= g.H) break;
-#pragma unroll 1
-            for (int hx = 0; hx < SF_TW; hx += 16) {
-                float4 tv[4], g2[4], b2[4], rv[4];
+        // This wave's pixels of the tile: rows wv and wv+4, 8 groups of 8 pixels (two 4-pixel steps).  The loads
+        // of group n+1 are issued before group n is consumed (two register buffers, statically named), so every
+        // wave keeps 6-8 KiB of HBM reads in flight while it gathers and modulates.
+        struct Buf { float4 tv[2], g2[2], b2[2], rv[2]; };
+        auto issue = [&](int grp, Buf& f) {
+            const int ly = wv + 4 * (grp >> 2), y = y0 + ly;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int x = x0 + hx + 4 * u + ps;
-                    tv[u] = zero4; g2[u] = zero4; b2[u] = zero4; rv[u] = zero4;
-                    if (x < g.W) {
-                        const size_t p = ((size_t)b * g.H + y) * g.W + x;
-                        tv[u] = ld_nt4(t + p * g.C + c);          // streamed once: keep it out of the way of D / halos
-                        g2[u] = ld_nt4(gb2 + p * 2 * g.C + c);
-                        b2[u] = ld_nt4(gb2 + p * 2 * g.C + g.C + c);
-                        if (residual) rv[u] = *(const float4*)(residual + p * g.C + c);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int lx = hx + 4 * u + ps, x = x0 + lx;
-                    if (x >= g.W) continue;
+            for (int u = 0; u < 2; ++u) {
+                const int x = x0 + 8 * (grp & 3) + 4 * u + ps;
+                f.tv[u] = zero4; f.g2[u] = zero4; f.b2[u] = zero4; f.rv[u] = zero4;
+                if (y < g.H && x < g.W) {
                     const size_t p = ((size_t)b * g.H + y) * g.W + x;
-                    float4 g1, b1;
-                    sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
-                    float4 o;
-                    o.x = (tv[u].x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * g2[u].x) + a_b * b1.x + (1.f - a_b) * b2[u].x + rv[u].x;
-                    o.y = (tv[u].y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * g2[u].y) + a_b * b1.y + (1.f - a_b) * b2[u].y + rv[u].y;
-                    o.z = (tv[u].z - mu.z) * sc.z * (1.f + a_g * g1.z + (1.f - a_g) * g2[u].z) + a_b * b1.z + (1.f - a_b) * b2[u].z + rv[u].z;
-                    o.w = (tv[u].w - mu.w) * sc.w * (1.f + a_g * g1.w + (1.f - a_g) * g2[u].w) + a_b * b1.w + (1.f - a_b) * b2[u].w + rv[u].w;
-                    if (relu) {
-                        o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
-                        o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
-                    }
-                    *(float4*)(out + p * g.C + c) = o;
+                    f.tv[u] = ld_nt4(t + p * g.C + c);      // streamed once: keep it out of the way of D / halos
+                    f.g2[u] = ld_nt4(gb2 + p * 2 * g.C + c);
+                    f.b2[u] = ld_nt4(gb2 + p * 2 * g.C + g.C + c);
+                    if (residual) f.rv[u] = *(const float4*)(residual + p * g.C + c);
                 }
             }
+        };
+        auto consume = [&](int grp, const Buf& f) {
+            const int ly = wv + 4 * (grp >> 2), y = y0 + ly;
+            if (y >= g.H) return;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int lx = 8 * (grp & 3) + 4 * u + ps, x = x0 + lx;
+                if (x >= g.W) continue;
+                const size_t p = ((size_t)b * g.H + y) * g.W + x;
+                float4 g1, b1;
+                sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
+                float4 o;
+                o.x = (f.tv[u].x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * f.g2[u].x) + a_b * b1.x + (1.f - a_b) * f.b2[u].x + f.rv[u].x;
+                o.y = (f.tv[u].y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * f.g2[u].y) + a_b * b1.y + (1.f - a_b) * f.b2[u].y + f.rv[u].y;
+                o.z = (f.tv[u].z - mu.z) * sc.z * (1.f + a_g * g1.z + (1.f - a_g) * f.g2[u].z) + a_b * b1.z + (1.f - a_b) * f.b2[u].z + f.rv[u].z;
+                o.w = (f.tv[u].w - mu.w) * sc.w * (1.f + a_g * g1.w + (1.f - a_g) * f.g2[u].w) + a_b * b1.w + (1.f - a_b) * f.b2[u].w + f.rv[u].w;
+                if (relu) {
+                    o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                    o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+                }
+                *(float4*)(out + p * g.C + c) = o;
+            }
+        };
+        Buf fa, fb;
+        issue(0, fa);
+#pragma unroll 1
+        for (int grp = 0; grp < 8; grp += 2) {
+            issue(grp + 1, fb);
+            consume(grp, fa);
+            if (grp + 2 < 8) issue(grp + 2, fa);
+            consume(grp + 1, fb);
         }
     }
 }
