@@ -35,7 +35,6 @@ struct ConvMfmaArgs {
     float* y;
     int B, H, W, Cin, Cout;
     int act, ps_r, accumulate;
-    int nitems, items_per_wg;
 };
 
 template <int NT, int WMODE>
@@ -46,28 +45,9 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
     constexpr int NTILE = 32 * NT;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int tiles_x = (a.W + CM_TW - 1) / CM_TW, tiles_y = (a.H + CM_TH - 1) / CM_TH;
-    const int nz = a.Cout / NTILE, nchunks = a.Cin / CM_CK;
-
-    // Persistent workgroup: a contiguous range of work items (sample, pixel tile, output-channel slice); the slice
-    // index varies fastest so that the workgroups sharing an input tile run back to back.  The (item, chunk) pairs
-    // form ONE software pipeline: the global loads of the next chunk - or of the next item's first chunk - are
-    // issued into registers before the MFMA work of the current chunk and written to LDS after it ("issue early /
-    // write late"), so load latency and the epilogue stores hide under matrix work.
-    const int first = blockIdx.x * a.items_per_wg;
-    int last = first + a.items_per_wg;
-    if (last > a.nitems) last = a.nitems;
-    if (first >= last) return;
-    struct Item { int b, x0, y0, n0; };
-    auto decode = [&](int w) {
-        Item t;
-        t.n0 = (w % nz) * NTILE;
-        const int tile = (w / nz) % (tiles_x * tiles_y);
-        t.b = w / (nz * tiles_x * tiles_y);
-        t.x0 = (tile % tiles_x) * CM_TW;
-        t.y0 = (tile / tiles_x) * CM_TH;
-        return t;
-    };
+    const int tiles_x = (a.W + CM_TW - 1) / CM_TW;
+    const int x0 = (blockIdx.x % tiles_x) * CM_TW, y0 = (blockIdx.x / tiles_x) * CM_TH;
+    const int b = blockIdx.y, n0 = blockIdx.z * NTILE;
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -77,20 +57,23 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+    // Software pipeline over the 16-channel chunks: the global loads of chunk c+1 are issued into registers before
+    // the MFMA work of chunk c starts and are written to LDS after it (split "issue early / write late" staging),
+    // so their latency hides under this workgroup's own matrix work instead of relying on the co-resident one.
     constexpr int NIN = (CM_HALO_H * CM_HALO_W * 4 + 255) / 256;
     constexpr int NWT = (9 * NTILE * 4 + 255) / 256;
     float4 pin[NIN], pwt[NWT];
     const float* wsrc = WMODE == 0 ? a.w + (size_t)9 * a.Cin * a.Cout : a.w;
-    auto prefetch = [&](const Item& t, int c0) {
+    auto prefetch = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
             const int idx = tid + 256 * u;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < CM_HALO_H * CM_HALO_W * 4) {
                 const int pix = idx >> 2, q4 = idx & 3;
-                const int gy = t.y0 + pix / CM_HALO_W - 1, gx = t.x0 + pix % CM_HALO_W - 1;
+                const int gy = y0 + pix / CM_HALO_W - 1, gx = x0 + pix % CM_HALO_W - 1;
                 if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *(const float4*)(a.x + (((size_t)t.b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
+                    v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
             }
             pin[u] = v;
         }
@@ -104,7 +87,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
             if (idx < 9 * NTILE * 4) {
                 const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
                 const int tsrc = WMODE == 0 ? tap : 8 - tap;
-                v = *(const float4*)(wsrc + ((size_t)tsrc * a.Cout + t.n0 + nl) * a.Cin + c0 + 4 * q4);
+                v = *(const float4*)(wsrc + ((size_t)tsrc * a.Cout + n0 + nl) * a.Cin + c0 + 4 * q4);
             }
             pwt[u] = v;
         }
@@ -124,58 +107,12 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
             }
         }
     };
-    const int rr = a.ps_r * a.ps_r;
-    auto epilogue = [&](const Item& t) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int gy = t.y0 + 2 * wv + m;
-            if (gy < a.H) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int co = t.n0 + 32 * n + li;
-                    const float bv = a.bias ? a.bias[co] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int gx = t.x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (gx >= a.W) continue;
-                        const size_t pidx = (((size_t)t.b * a.H + gy) * a.W + gx) * a.Cout + co;
-                        float v = acc[m][n][r] + bv;
-                        if (a.residual) v += a.residual[pidx];
-                        v = dasr_act(v, a.act);
-                        size_t o = pidx;
-                        if (a.ps_r > 1) {
-                            int c = co / rr, i = (co / a.ps_r) % a.ps_r, j = co % a.ps_r;
-                            o = (((size_t)t.b * a.H * a.ps_r + (size_t)gy * a.ps_r + i) * ((size_t)a.W * a.ps_r) +
-                                 (size_t)gx * a.ps_r + j) * (a.Cout / rr) + c;
-                        }
-                        if (a.accumulate) v += a.y[o];
-                        a.y[o] = v;
-                    }
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        }
-    };
-
-    Item cur = decode(first);
-    prefetch(cur, 0);
-    const int total = (last - first) * nchunks;
-    int ch = 0, wi = first;
-    for (int it = 0; it < total; ++it) {
+    prefetch(0);
+    for (int c0 = 0; c0 < a.Cin; c0 += CM_CK) {
         __syncthreads();                       // every wave is done reading the previous chunk
         commit();
         __syncthreads();
-        if (it + 1 < total) {
-            if (ch + 1 < nchunks) {
-                prefetch(cur, (ch + 1) * CM_CK);
-            } else {
-                const Item nx = decode(wi + 1);
-                prefetch(nx, 0);
-            }
-        }
+        if (c0 + CM_CK < a.Cin) prefetch(c0 + CM_CK);
         // ---- 9 taps x 16 channels = 72 K=2 steps per accumulator
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
@@ -200,11 +137,34 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
                     }
             }
         }
-        if (++ch == nchunks) {
-            epilogue(cur);
-            ch = 0;
-            ++wi;
-            if (wi < last) cur = decode(wi);
+    }
+    // ---- epilogue
+    const int rr = a.ps_r * a.ps_r;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int gy = y0 + 2 * wv + m;
+        if (gy >= a.H) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n0 + 32 * n + li;
+            const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (gx >= a.W) continue;
+                const size_t pidx = (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co;
+                float v = acc[m][n][r] + bv;
+                if (a.residual) v += a.residual[pidx];
+                v = dasr_act(v, a.act);
+                size_t o = pidx;
+                if (a.ps_r > 1) {
+                    int c = co / rr, i = (co / a.ps_r) % a.ps_r, j = co % a.ps_r;
+                    o = (((size_t)b * a.H * a.ps_r + (size_t)gy * a.ps_r + i) * ((size_t)a.W * a.ps_r) +
+                         (size_t)gx * a.ps_r + j) * (a.Cout / rr) + c;
+                }
+                if (a.accumulate) v += a.y[o];
+                a.y[o] = v;
+            }
         }
     }
 }
@@ -220,29 +180,24 @@ bool conv_mfma_supported(const ConvGeom& g) {
 
 template <int WMODE>
 static int launch_conv_mfma(ConvMfmaArgs& a, void* stream) {
-    const int tiles = ((a.W + CM_TW - 1) / CM_TW) * ((a.H + CM_TH - 1) / CM_TH);
-    const int NT = (a.Cout % 64) == 0 ? 2 : 1;
-    a.nitems = tiles * a.B * (a.Cout / (32 * NT));
-    const int slots = 256 * (NT == 2 ? 2 : 3);       // resident workgroups: 73 KB (NT=2) / 50 KB (NT=1) of LDS each
-    a.items_per_wg = (a.nitems + slots - 1) / slots;
-    const unsigned grid = (unsigned)((a.nitems + a.items_per_wg - 1) / a.items_per_wg);
-    if (NT == 2) {
-        DASR_LAUNCH((k_conv3x3_mfma<2, WMODE>), dim3(grid), dim3(256), conv_mfma_lds(2), stream, a);
+    int tiles = ((a.W + CM_TW - 1) / CM_TW) * ((a.H + CM_TH - 1) / CM_TH);
+    if ((a.Cout % 64) == 0) {
+        DASR_LAUNCH((k_conv3x3_mfma<2, WMODE>), dim3(tiles, a.B, a.Cout / 64), dim3(256), conv_mfma_lds(2), stream, a);
     } else {
-        DASR_LAUNCH((k_conv3x3_mfma<1, WMODE>), dim3(grid), dim3(256), conv_mfma_lds(1), stream, a);
+        DASR_LAUNCH((k_conv3x3_mfma<1, WMODE>), dim3(tiles, a.B, a.Cout / 32), dim3(256), conv_mfma_lds(1), stream, a);
     }
     DASR_RETURN_LAUNCH_STATUS();
 }
 
 int conv_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
                   float* y, int act, int ps_r, void* stream) {
-    ConvMfmaArgs a{x, w, bias, residual, y, g.B, g.H, g.W, g.Cin, g.Cout, act, ps_r, 0, 0, 0};
+    ConvMfmaArgs a{x, w, bias, residual, y, g.B, g.H, g.W, g.Cin, g.Cout, act, ps_r, 0};
     return launch_conv_mfma<0>(a, stream);
 }
 
 // dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * W[tap][ci][co]: a 3x3 conv of dconv (channels Cout) to Cin
 int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream) {
-    ConvMfmaArgs a{dconv, w, nullptr, nullptr, dx, g.B, g.H, g.W, g.Cout, g.Cin, DASR_ACT_NONE, 1, accumulate, 0, 0};
+    ConvMfmaArgs a{dconv, w, nullptr, nullptr, dx, g.B, g.H, g.W, g.Cout, g.Cin, DASR_ACT_NONE, 1, accumulate};
     return launch_conv_mfma<1>(a, stream);
 }
 bool conv_mfma_dgrad_supported(const ConvGeom& g) {
