@@ -32,6 +32,57 @@ def cosine_restart_lr(step, base_lr=1e-3, T_period=(20000, 20000, 20000, 20000),
     return eta_min + (base_lr * w - eta_min) * (1 + math.cos(math.pi * (step - last_restart) / T)) / 2
 
 
+class _RegionSums(torch.autograd.Function):
+    """sums = (K smooth-L1 numerators | K areas | sum|sr-hr|) in ONE pass over sr, hr (dasr_loss_sums); the
+    backward is one elementwise pass (dasr_loss_bwd).  One-hot masks only (region bytes from dasr_mask_compress)."""
+
+    @staticmethod
+    def forward(ctx, sr, hr, region, K):
+        from . import ops
+        sr_c, hr_c = sr.contiguous(), hr.contiguous()
+        ctx.save_for_backward(sr_c, hr_c, region)
+        ctx.K = K
+        return ops.loss_sums(sr_c, hr_c, region, K)
+
+    @staticmethod
+    def backward(ctx, dsums):
+        from . import ops
+        sr, hr, region = ctx.saved_tensors
+        return ops.loss_bwd(sr, hr, region, dsums.contiguous(), ctx.K), None, None, None
+
+
+def fused_losses(sr, hr, mask_list, trainable_weight, pixel_weight, dynamic_weight, group=None):
+    """l_pix and l_dynamic from one pass over (sr, hr) on the GPU when the masks are one-hot, or None when they are
+    not (the caller then uses the PyTorch formulation).  Same values and gradients as nn.L1Loss +
+    dynamic_weight_mask_loss('smoothl1'); with a process group the region sums are made global first."""
+    from . import ops
+    if not sr.is_cuda or sr.dtype != torch.float32 or mask_list.shape[2] == 0:
+        return None
+    H, W = sr.shape[2:]
+    h, w = mask_list.shape[2:]
+    if H % h or W % w or H // h != W // w:
+        return None
+    region, flag = ops.mask_compress(mask_list.contiguous())
+    if int(flag.item()) != 0:
+        return None
+    K = mask_list.shape[1]
+    sums = _RegionSums.apply(sr, hr, region, K)
+    num, den, l1 = sums[:K], sums[K:2 * K].detach(), sums[2 * K]
+    world = torch.distributed.get_world_size(group) if (group is not None and torch.distributed.is_initialized()) else 1
+    l_pix = pixel_weight * l1 / sr.numel()
+    if world > 1:
+        gden, gnum = den.clone(), num.detach().clone()
+        torch.distributed.all_reduce(gden, group=group)
+        torch.distributed.all_reduce(gnum, group=group)
+        local = num / gden * world
+        per = gnum / gden + (local - local.detach())
+    else:
+        per = num / den
+    sm = F.softmax(trainable_weight, dim=0)
+    l_dyn = (sm * per).sum() * dynamic_weight
+    return l_pix, l_dyn, per, sm
+
+
 class DynamicMaskLoss(torch.nn.Module):
     """dynamic_weight_mask_loss with the 'smoothl1' criterion (mask_loss.py:44-90).
 
@@ -129,8 +180,14 @@ class Trainer:
         self.update_learning_rate()
         self.optimizer.zero_grad(set_to_none=True)
         sr = self.net(lq, depth, masks)
-        l_pix = self.l_pix_w * F.l1_loss(sr, gt)
-        per, weighted, l_dyn, sm = self.dynamic_loss(sr, gt, masks, self.group if self.world > 1 else None)
+        grp = self.group if self.world > 1 else None
+        fused = fused_losses(sr, gt, masks, self.dynamic_loss.trainable_weight, self.l_pix_w,
+                             self.dynamic_loss.l_mask_w, grp)
+        if fused is not None:
+            l_pix, l_dyn, per, sm = fused
+        else:
+            l_pix = self.l_pix_w * F.l1_loss(sr, gt)
+            per, weighted, l_dyn, sm = self.dynamic_loss(sr, gt, masks, grp)
         total = l_pix + l_dyn
         total.backward()
         self._allreduce_grads()

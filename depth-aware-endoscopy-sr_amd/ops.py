@@ -297,3 +297,22 @@ def region_pool_bwd(dout, maskr, area, feat_shape):
     dfeat = torch.empty(feat_shape, dtype=torch.float32, device=dout.device)
     _call("dasr_region_pool_bwd", _p(dout), _p(maskr), _p(area), _p(dfeat), B, K, L, h, w)
     return dfeat
+
+
+# ---- harness losses (one-hot masks) ------------------------------------------------------------
+def loss_sums(sr, hr, region, K):
+    B, C, H, W = sr.shape
+    _, h, w = region.shape
+    scale = H // h
+    assert H == h * scale and W == w * scale
+    sums = empty((2 * K + 1,), sr)
+    _call("dasr_loss_sums", _p(sr), _p(hr), _lib.ptr(region, dtype=torch.uint8), _p(sums), B, C, h, w, scale, K)
+    return sums
+
+
+def loss_bwd(sr, hr, region, dsums, K):
+    B, C, H, W = sr.shape
+    _, h, w = region.shape
+    dsr = torch.empty_like(sr)
+    _call("dasr_loss_bwd", _p(sr), _p(hr), _lib.ptr(region, dtype=torch.uint8), _p(dsums), _p(dsr), B, C, h, w, H // h, K)
+    return dsr

@@ -189,6 +189,17 @@ int dasr_region_pool_fwd(const float* feat, const float* mask, float* maskr, flo
 int dasr_region_pool_bwd(const float* dout, const float* maskr, const float* area, float* dfeat, int B, int K, int L,
                          int h, int w, void* stream);
 
+/* ---- harness losses in one pass (one-hot masks only) -------------------------------------
+ * nn.L1Loss + dynamic_weight_mask_loss('smoothl1') (F_model_depthCond.py:164,188-190; mask_loss.py:64-90) need, per
+ * depth region k, sum smooth_l1(m_k*sr, m_k*hr) and sum m_k (masks nearest-upsampled to HR), and sum |sr-hr|.
+ * sr, hr: NCHW [B,C,h*scale,w*scale]; region: bytes [B,h,w] from dasr_mask_compress.
+ * sums [2K+1] = K numerators | K areas (C * #pixels) | sum|sr-hr|.  Division / softmax weights stay in PyTorch.
+ * dasr_loss_bwd: dsr = dsums[2K]*sign(sr-hr) + dsums[region]*smooth_l1'(sr-hr)  (dsums: device [2K+1]). */
+int dasr_loss_sums(const float* sr, const float* hr, const unsigned char* region, float* sums, int B, int C, int h,
+                   int w, int scale, int K, void* stream);
+int dasr_loss_bwd(const float* sr, const float* hr, const unsigned char* region, const float* dsums, float* dsr, int B,
+                  int C, int h, int w, int scale, int K, void* stream);
+
 /* ---- small elementwise helpers ---------------------------------------------------------------- */
 int dasr_add(const float* a, const float* b, float* out, size_t n, void* stream);  /* torch.add, sftmd_arch.py:931 */
 int dasr_accumulate(float* dst, const float* src, size_t n, void* stream);         /* dst += src (gradient fan-in) */

@@ -341,3 +341,30 @@ def check_encoder_geometry(device):
         assert np.abs(nchw(e1.data).cpu().numpy() - g["feat"]).max() <= 2e-6
         assert np.abs(nchw(e5.data).cpu().numpy() - g["l5"]).max() <= 5e-6
         assert np.abs(st.data.cpu().numpy() - g["vec"]).max() <= 5e-6
+
+
+def check_fused_loss(device):
+    """dasr_loss_sums / dasr_loss_bwd vs the oracle's L1 + dynamic loss (values and d/dsr, d/dw)."""
+    from dasr_amd import harness
+    for (B, h, w, s) in [(2, 6, 7, 8), (1, 5, 9, 2), (2, 4, 5, 3)]:
+        lq, gt, dm, mk = synth.seeded_batch(7, B, h, w, s)
+        gen = torch.Generator().manual_seed(3)
+        sr = (gt + 0.6 * torch.randn(gt.shape, generator=gen)).clamp(-1, 2)
+        sr[0, 0, 0, :3] += 3.0                        # |d| > 1: the linear branch of smooth-L1
+        sr_o = sr.clone().requires_grad_(True)
+        w_o = (1.0 + 0.1 * torch.arange(10, dtype=torch.float32)).requires_grad_(True)
+        total_o, l_pix_o, l_dyn_o, per_o = O.total_loss(sr_o, gt, mk, w_o)
+        total_o.backward()
+        region, flag = ops.mask_compress(mk.contiguous().to(device))
+        assert int(flag.item()) == 0
+        sr_d = sr.clone().to(device).requires_grad_(True)
+        w_d = w_o.detach().clone().to(device).requires_grad_(True)
+        sums = harness._RegionSums.apply(sr_d, gt.to(device), region, 10)
+        num, den, l1 = sums[:10], sums[10:20].detach(), sums[20]
+        l_pix = l1 / sr.numel()
+        l_dyn = (F.softmax(w_d, 0) * (num / den)).sum() * 10.0
+        (l_pix + l_dyn).backward()
+        assert abs(l_pix.item() - l_pix_o.item()) <= 2e-6 * max(1, abs(l_pix_o.item()))
+        assert abs(l_dyn.item() - l_dyn_o.item()) <= 2e-5 * max(1, abs(l_dyn_o.item()))
+        assert rel_max(sr_d.grad, sr_o.grad) <= 2e-5
+        assert rel_max(w_d.grad, w_o.grad) <= 2e-5

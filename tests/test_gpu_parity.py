@@ -40,6 +40,10 @@ def test_blocks():
     pc.check_blocks("cuda")
 
 
+def test_fused_loss():
+    pc.check_fused_loss("cuda")
+
+
 def test_encoder_geometry():
     pc.check_encoder_geometry("cuda")
 

@@ -28,6 +28,10 @@ def test_blocks(emu):
     pc.check_blocks("cpu")
 
 
+def test_fused_loss(emu):
+    pc.check_fused_loss("cpu")
+
+
 def test_encoder_geometry(emu):
     pc.check_encoder_geometry("cpu")
 
