@@ -20,12 +20,10 @@
 #include "dasr_common.h"
 #include "conv_kernels.h"
 
-#define CM_TH 8
 #define CM_TW 32
 #define CM_CK 16
 #define CM_CKP 20
 #define CM_HALO_W (CM_TW + 2)
-#define CM_HALO_H (CM_TH + 2)
 
 struct ConvMfmaArgs {
     const float* x;         // [B,H,W,Cin]
@@ -37,9 +35,14 @@ struct ConvMfmaArgs {
     int act, ps_r, accumulate;
 };
 
-template <int NT, int WMODE>
-__global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
+// CM_TH = tile rows = 2 x waves per workgroup (8 rows / 256 threads, or 16 rows / 512 threads: the 16-row tile
+// stages each weight slice once for twice the pixels - weights are ~60 % of the staged bytes - and still keeps
+// two waves per SIMD with a single workgroup per CU).
+template <int NT, int WMODE, int CM_TH>
+__global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
     DASR_DYN_SMEM(smem);
+    constexpr int CM_HALO_H = CM_TH + 2;
+    constexpr int NTHR = 32 * CM_TH;
     float* sIn = (float*)smem;                                // [HALO_H*HALO_W][CKP]
     float* sW = sIn + CM_HALO_H * CM_HALO_W * CM_CKP;         // [9][32*NT][CKP]
     constexpr int NTILE = 32 * NT;
@@ -60,14 +63,14 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
     // Software pipeline over the 16-channel chunks: the global loads of chunk c+1 are issued into registers before
     // the MFMA work of chunk c starts and are written to LDS after it (split "issue early / write late" staging),
     // so their latency hides under this workgroup's own matrix work instead of relying on the co-resident one.
-    constexpr int NIN = (CM_HALO_H * CM_HALO_W * 4 + 255) / 256;
-    constexpr int NWT = (9 * NTILE * 4 + 255) / 256;
+    constexpr int NIN = (CM_HALO_H * CM_HALO_W * 4 + NTHR - 1) / NTHR;
+    constexpr int NWT = (9 * NTILE * 4 + NTHR - 1) / NTHR;
     float4 pin[NIN], pwt[NWT];
     const float* wsrc = WMODE == 0 ? a.w + (size_t)9 * a.Cin * a.Cout : a.w;
     auto prefetch = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
-            const int idx = tid + 256 * u;
+            const int idx = tid + NTHR * u;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < CM_HALO_H * CM_HALO_W * 4) {
                 const int pix = idx >> 2, q4 = idx & 3;
@@ -82,7 +85,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
         //   dgrad  : first half (HWIO of the forward conv = [tap][n = ci_f][k = co_f]) with the taps flipped
 #pragma unroll
         for (int u = 0; u < NWT; ++u) {
-            const int idx = tid + 256 * u;
+            const int idx = tid + NTHR * u;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < 9 * NTILE * 4) {
                 const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
@@ -95,12 +98,12 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
     auto commit = [&]() {
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
-            const int idx = tid + 256 * u;
+            const int idx = tid + NTHR * u;
             if (idx < CM_HALO_H * CM_HALO_W * 4) *(float4*)(sIn + (idx >> 2) * CM_CKP + 4 * (idx & 3)) = pin[u];
         }
 #pragma unroll
         for (int u = 0; u < NWT; ++u) {
-            const int idx = tid + 256 * u;
+            const int idx = tid + NTHR * u;
             if (idx < 9 * NTILE * 4) {
                 const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
                 *(float4*)(sW + (tap * NTILE + nl) * CM_CKP + 4 * q4) = pwt[u];
@@ -169,8 +172,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(ConvMfmaArgs a) {
     }
 }
 
-static size_t conv_mfma_lds(int NT) {
-    return sizeof(float) * (size_t)(CM_HALO_H * CM_HALO_W * CM_CKP + 9 * 32 * NT * CM_CKP);
+static size_t conv_mfma_lds(int NT, int TH) {
+    return sizeof(float) * (size_t)((TH + 2) * CM_HALO_W * CM_CKP + 9 * 32 * NT * CM_CKP);
 }
 
 bool conv_mfma_supported(const ConvGeom& g) {
@@ -180,11 +183,24 @@ bool conv_mfma_supported(const ConvGeom& g) {
 
 template <int WMODE>
 static int launch_conv_mfma(ConvMfmaArgs& a, void* stream) {
-    int tiles = ((a.W + CM_TW - 1) / CM_TW) * ((a.H + CM_TH - 1) / CM_TH);
+    const int TH = (a.H % 16) == 0 ? 16 : 8;
+    int tiles = ((a.W + CM_TW - 1) / CM_TW) * ((a.H + TH - 1) / TH);
     if ((a.Cout % 64) == 0) {
-        DASR_LAUNCH((k_conv3x3_mfma<2, WMODE>), dim3(tiles, a.B, a.Cout / 64), dim3(256), conv_mfma_lds(2), stream, a);
+        if (TH == 16) {
+            DASR_LAUNCH((k_conv3x3_mfma<2, WMODE, 16>), dim3(tiles, a.B, a.Cout / 64), dim3(512), conv_mfma_lds(2, 16),
+                        stream, a);
+        } else {
+            DASR_LAUNCH((k_conv3x3_mfma<2, WMODE, 8>), dim3(tiles, a.B, a.Cout / 64), dim3(256), conv_mfma_lds(2, 8),
+                        stream, a);
+        }
     } else {
-        DASR_LAUNCH((k_conv3x3_mfma<1, WMODE>), dim3(tiles, a.B, a.Cout / 32), dim3(256), conv_mfma_lds(1), stream, a);
+        if (TH == 16) {
+            DASR_LAUNCH((k_conv3x3_mfma<1, WMODE, 16>), dim3(tiles, a.B, a.Cout / 32), dim3(512), conv_mfma_lds(1, 16),
+                        stream, a);
+        } else {
+            DASR_LAUNCH((k_conv3x3_mfma<1, WMODE, 8>), dim3(tiles, a.B, a.Cout / 32), dim3(256), conv_mfma_lds(1, 8),
+                        stream, a);
+        }
     }
     DASR_RETURN_LAUNCH_STATUS();
 }

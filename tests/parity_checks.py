@@ -123,6 +123,8 @@ def check_conv_variants(device, seed=0):
         (32, 64, 3, 2, 1, False, 2, 1, False, 16, 20), (64, 128, 3, 2, 1, False, 2, 1, False, 9, 11),
         (128, 64, 3, 2, 1, True, 2, 1, False, 5, 6), (64, 64, 3, 2, 1, False, 0, 1, False, 11, 13),
         (8, 32, 3, 1, 1, False, 1, 1, False, 7, 9),
+        (64, 64, 3, 1, 1, False, 2, 1, False, 16, 33), (32, 32, 3, 1, 1, False, 1, 1, True, 32, 20),
+        (16, 128, 3, 1, 1, False, 2, 2, False, 16, 40),
     ]
     worst = 0.0
     for (cin, cout, k, stride, pad, tr, act, ps, res, H, W) in cases:
