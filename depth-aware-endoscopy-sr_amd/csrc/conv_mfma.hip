@@ -116,29 +116,38 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
         commit();
         __syncthreads();
         if (c0 + CM_CK < a.Cin) prefetch(c0 + CM_CK);
-        // ---- 9 taps x 16 channels = 72 K=2 steps per accumulator
+        // ---- 9 taps x 16 channels = 18 fragment steps of 4 K=2 MFMAs per accumulator.  The LDS reads of step j+1
+        // are issued before the MFMAs of step j (two statically named fragment sets), so the matrix pipe never
+        // waits for a ds_read at the start of a step.
+        auto ldfrag = [&](int j, float4 (&A)[2], float4 (&Bf)[NT]) {
+            const int tap = j >> 1, q = j & 1;
+            const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                A[m] = *(const float4*)(sIn + ((2 * wv + m + dy) * CM_HALO_W + li + dx) * CM_CKP + 8 * q + 4 * lh);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                Bf[n] = *(const float4*)(sW + (tap * NTILE + 32 * n + li) * CM_CKP + 8 * q + 4 * lh);
+        };
+        auto mma = [&](const float4 (&A)[2], const float4 (&Bf)[NT]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].x, Bf[n].x, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].y, Bf[n].y, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].z, Bf[n].z, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].w, Bf[n].w, acc[m][n], 0, 0, 0);
+                }
+        };
+        float4 A0[2], B0[NT], A1[2], B1[NT];
+        ldfrag(0, A0, B0);
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float4 A[2], Bf[NT];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    A[m] = *(const float4*)(sIn + ((2 * wv + m + dy) * CM_HALO_W + li + dx) * CM_CKP + 8 * q + 4 * lh);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    Bf[n] = *(const float4*)(sW + (tap * NTILE + 32 * n + li) * CM_CKP + 8 * q + 4 * lh);
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].x, Bf[n].x, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].y, Bf[n].y, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].z, Bf[n].z, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m].w, Bf[n].w, acc[m][n], 0, 0, 0);
-                    }
-            }
+        for (int j = 0; j < 18; j += 2) {
+            ldfrag(j + 1, A1, B1);
+            mma(A0, B0);
+            if (j + 2 < 18) ldfrag(j + 2, A0, B0);
+            mma(A1, B1);
         }
     }
     // ---- epilogue
@@ -301,20 +310,31 @@ __global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
             aoff[t] = ((tt / 3) * (WG_TW + 2) + tt % 3) * CIG + 32 * mt + li;
             amask[t] = tap < 9 ? 1.f : 0.f;
         }
-#pragma unroll 2
-        for (int s = 0; s < WG_TH * WG_TW / 2; ++s) {
+        auto ldk = [&](int s, float& bv, float (&av)[NACC]) {
             const int py = s / (WG_TW / 2), px = 2 * (s % (WG_TW / 2)) + lh;
-            const float bv = sD[(py * WG_TW + px) * COG + 32 * nt + li];
+            bv = sD[(py * WG_TW + px) * COG + 32 * nt + li];
             const float* xs = sX + (py * (WG_TW + 2) + px) * CIG;
-            float av[NACC];
 #pragma unroll
             for (int t = 0; t < NACC; ++t) av[t] = xs[aoff[t]];
+        };
+        auto mmak = [&](float bv, float (&av)[NACC]) {
             if (G > 1) {
 #pragma unroll
                 for (int t = 0; t < NACC; ++t) av[t] *= amask[t];
             }
 #pragma unroll
             for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+        };
+        // two statically named fragment sets: the LDS reads of pixel pair s+1 are in flight during the MFMAs of pair s
+        float bv0, bv1, av0[NACC], av1[NACC];
+        constexpr int NS = WG_TH * WG_TW / 2;
+        ldk(0, bv0, av0);
+#pragma unroll 1
+        for (int s = 0; s < NS; s += 2) {
+            ldk(s + 1, bv1, av1);
+            mmak(bv0, av0);
+            if (s + 2 < NS) ldk(s + 2, bv0, av0);
+            mmak(bv1, av1);
         }
     }
     if (do_bias) atomicAdd(&a.dbias[co0 + tid], bsum);
