@@ -211,7 +211,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "sean_fwd_pmc.json")
         if os.path.exists(pmc):
             try:
-                roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if rec.get("B") == B:          # counters were collected at this launch size
+                    roof["traffic"] = int(rec.get("hbm_bytes_per_launch"))
             except Exception:
                 pass
 
