@@ -28,6 +28,8 @@ struct Conv9Args {
     float* out;          // fwd: y [B,H,W,Cout]; dgrad: dx [B,H,W,Cin]; wgrad: slabs
     int B, H, W, Cin, Cout;
     int accumulate, P, ntiles;
+    const float* mask_src;   // dgrad: see ConvMfmaArgs::mask_src (conv_mfma.hip)
+    int mask_act, unps_r;
 };
 
 // ------------------------------------------------------------------------------------------ forward
@@ -175,6 +177,12 @@ __global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
             if (gx >= a.W) continue;
             size_t o = (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + n0 + li;
             float v = acc[t][g];
+            if (a.mask_src) v *= dasr_act_grad_from_out(a.mask_src[o], a.mask_act);
+            if (a.unps_r > 1) {
+                const int ur = a.unps_r;
+                o = ((((size_t)b * (a.H / ur) + gy / ur) * (a.W / ur) + gx / ur) * a.Cin + n0 + li) * (ur * ur) +
+                    (gy % ur) * ur + (gx % ur);
+            }
             if (a.accumulate) v += a.out[o];
             a.out[o] = v;
         }
@@ -254,15 +262,17 @@ bool conv9_mfma_supported(const ConvGeom& g) {
            g.Cout >= 1 && g.Cout <= 3 && g.H == g.Ho && g.W == g.Wo;
 }
 int conv9_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* stream) {
-    Conv9Args a{x, w, bias, nullptr, y, g.B, g.H, g.W, g.Cin, g.Cout, 0, 0, 0};
+    Conv9Args a{x, w, bias, nullptr, y, g.B, g.H, g.W, g.Cin, g.Cout, 0, 0, 0, nullptr, 0, 1};
     int TWO = C9_TQ - 8;
     int tiles = ((g.W + TWO - 1) / TWO) * ((g.H + C9_TH - 1) / C9_TH);
     size_t lds = sizeof(float) * (size_t)((C9_TH + 8) * C9_TQ * C9_CKP + 9 * 32 * C9_CKP);
     DASR_LAUNCH(k_conv9x9_fwd_mfma, dim3(tiles, g.B), dim3(256), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
 }
-int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream) {
-    Conv9Args a{nullptr, w, nullptr, dconv, dx, g.B, g.H, g.W, g.Cin, g.Cout, accumulate, 0, 0};
+int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate,
+                     const float* mask_src, int mask_act, int unps_r, void* stream) {
+    Conv9Args a{nullptr, w, nullptr, dconv, dx, g.B, g.H, g.W, g.Cin, g.Cout, accumulate, 0, 0,
+                mask_src, mask_act, unps_r < 1 ? 1 : unps_r};
     int tiles = ((g.W + C9_TQ - 1) / C9_TQ) * ((g.H + C9_TH - 1) / C9_TH);
     size_t lds = sizeof(float) * (size_t)((C9_TH + 8) * C9_DYW + 9 * 28 * 32);
     DASR_LAUNCH(k_conv9x9_dgrad_mfma, dim3(tiles, g.B, g.Cin / 32), dim3(256), lds, stream, a);
@@ -282,7 +292,7 @@ size_t conv9_mfma_wgrad_workspace(const ConvGeom& g) {
 int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream) {
     int ntiles, P;
     conv9_wgrad_plan(g, ntiles, P);
-    Conv9Args a{x, nullptr, nullptr, dconv, (float*)workspace, g.B, g.H, g.W, g.Cin, g.Cout, 0, P, ntiles};
+    Conv9Args a{x, nullptr, nullptr, dconv, (float*)workspace, g.B, g.H, g.W, g.Cin, g.Cout, 0, P, ntiles, nullptr, 0, 1};
     size_t lds = sizeof(float) * (size_t)(C9_TH * C9_TQ * 32 + (C9_TH + 8) * C9_DYW);
     DASR_LAUNCH(k_conv9x9_wgrad_mfma, dim3(g.Cin / 32, P), dim3(256), lds, stream, a);
     int n = 81 * g.Cin * g.Cout;

@@ -55,8 +55,8 @@ extern "C" int dasr_conv2d_dgrad(const float* dconv, const float* w, float* dx, 
     ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
     int rc = check_geom(g);
     if (rc) return rc;
-    if (conv_mfma_dgrad_supported(g)) return conv_mfma_dgrad(g, dconv, w, dx, accumulate, stream);
-    if (conv9_mfma_supported(g)) return conv9_mfma_dgrad(g, dconv, w, dx, accumulate, stream);
+    if (conv_mfma_dgrad_supported(g)) return conv_mfma_dgrad(g, dconv, w, dx, accumulate, nullptr, 0, 1, stream);
+    if (conv9_mfma_supported(g)) return conv9_mfma_dgrad(g, dconv, w, dx, accumulate, nullptr, 0, 1, stream);
     if (conv_gather_dgrad_supported(g)) return conv_gather_dgrad(g, dconv, w, dx, accumulate, stream);
     return conv_direct_dgrad(g, dconv, w, dx, accumulate, stream);
 }
@@ -114,4 +114,26 @@ extern "C" int dasr_conv2d_wgrad_act(const float* x, const float* dy, const floa
     if (rc) return rc;
     return dasr_conv2d_wgrad(x, dconv_scratch, dw, dbias, workspace, workspace_bytes, B, H, W, Cin, Ho, Wo, Cout, KH, KW,
                              stride, pad, transposed, stream);
+}
+
+// 1 when dasr_conv2d_dgrad_act has a kernel for this geometry
+extern "C" int dasr_conv2d_dgrad_act_supported(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                               int stride, int pad, int transposed, int ps_r) {
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    if (check_geom(g) != DASR_OK) return 0;
+    if (ps_r < 1) ps_r = 1;
+    if ((H % ps_r) != 0 || (W % ps_r) != 0) return 0;
+    return (conv_mfma_dgrad_supported(g) || conv9_mfma_supported(g)) ? 1 : 0;
+}
+
+extern "C" int dasr_conv2d_dgrad_act(const float* dconv, const float* w, const float* x_act, float* dprev, int B, int H,
+                                     int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                                     int transposed, int act, int ps_r, void* stream) {
+    DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(w); DASR_CHECK_PTR(x_act); DASR_CHECK_PTR(dprev);
+    if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
+    if (!dasr_conv2d_dgrad_act_supported(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed, ps_r))
+        return DASR_E_UNSUPPORTED;
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    if (conv_mfma_dgrad_supported(g)) return conv_mfma_dgrad(g, dconv, w, dprev, 0, x_act, act, ps_r, stream);
+    return conv9_mfma_dgrad(g, dconv, w, dprev, 0, x_act, act, ps_r, stream);
 }

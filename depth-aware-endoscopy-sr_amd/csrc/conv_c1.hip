@@ -48,24 +48,41 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restric
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t npix = (size_t)B * H * W;
+    const size_t stride = (size_t)gridDim.x * npl;
     if (pl < npl)
-        for (size_t p = (size_t)blockIdx.x * npl + pl; p < npix; p += (size_t)gridDim.x * npl) {
-            const int px = (int)(p % W), py = (int)((p / W) % H);
-            const size_t b = p / ((size_t)W * H);
-            const float* xb = x + b * (size_t)H * W;
-            float4 g = *(const float4*)(dy + p * Cout + 4 * q);
-            if (yact) {
-                const float4 yv = *(const float4*)(yact + p * Cout + 4 * q);
-                g.x *= dasr_act_grad_from_out(yv.x, act); g.y *= dasr_act_grad_from_out(yv.y, act);
-                g.z *= dasr_act_grad_from_out(yv.z, act); g.w *= dasr_act_grad_from_out(yv.w, act);
-            }
-            acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
+        for (size_t p0 = (size_t)blockIdx.x * npl + pl; p0 < npix; p0 += 4 * stride) {
+            // four pixels per trip: all eight 16-byte loads are issued before the first is consumed
+            float4 gq[4], yq[4];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
-                const float d = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[(size_t)iy * W + ix] : 0.f;
-                acc[t].x = fmaf(d, g.x, acc[t].x); acc[t].y = fmaf(d, g.y, acc[t].y);
-                acc[t].z = fmaf(d, g.z, acc[t].z); acc[t].w = fmaf(d, g.w, acc[t].w);
+            for (int u = 0; u < 4; ++u) {
+                const size_t p = p0 + u * stride;
+                gq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                yq[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (p < npix) {
+                    gq[u] = *(const float4*)(dy + p * Cout + 4 * q);
+                    if (yact) yq[u] = *(const float4*)(yact + p * Cout + 4 * q);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t p = p0 + u * stride;
+                if (p >= npix) continue;
+                const int px = (int)(p % W), py = (int)((p / W) % H);
+                const size_t b = p / ((size_t)W * H);
+                const float* xb = x + b * (size_t)H * W;
+                float4 g = gq[u];
+                if (yact) {
+                    g.x *= dasr_act_grad_from_out(yq[u].x, act); g.y *= dasr_act_grad_from_out(yq[u].y, act);
+                    g.z *= dasr_act_grad_from_out(yq[u].z, act); g.w *= dasr_act_grad_from_out(yq[u].w, act);
+                }
+                acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
+                    const float d = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[(size_t)iy * W + ix] : 0.f;
+                    acc[t].x = fmaf(d, g.x, acc[t].x); acc[t].y = fmaf(d, g.y, acc[t].y);
+                    acc[t].z = fmaf(d, g.z, acc[t].z); acc[t].w = fmaf(d, g.w, acc[t].w);
+                }
             }
         }
     // reduce over the pixel lanes of the workgroup, then one float atomic per output per workgroup
@@ -99,7 +116,7 @@ int conv_c1_wgrad(const ConvGeom& g, const float* x, const float* dy, const floa
     hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * 9 * g.Cout, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     if (dbias && (e = hipMemsetAsync(dbias, 0, sizeof(float) * g.Cout, (hipStream_t)stream)) != hipSuccess) return (int)e;
-    DASR_LAUNCH(k_conv3x3_c1_wgrad, dim3(512), dim3(256), sizeof(float) * 256 * 40, stream, x, dy, yact, dw, dbias, g.B,
+    DASR_LAUNCH(k_conv3x3_c1_wgrad, dim3(1024), dim3(256), sizeof(float) * 256 * 40, stream, x, dy, yact, dw, dbias, g.B,
                 g.H, g.W, g.Cout, act);
     DASR_RETURN_LAUNCH_STATUS();
 }

@@ -31,7 +31,8 @@ bool conv_mfma_dgrad_supported(const ConvGeom& g);
 bool conv_mfma_wgrad_supported(const ConvGeom& g);
 int conv_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
                   float* y, int act, int ps_r, void* stream);
-int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
+int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate,
+                    const float* mask_src, int mask_act, int unps_r, void* stream);
 size_t conv_mfma_wgrad_workspace(const ConvGeom& g);
 int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
                     void* stream);   // dbias (may be null) is produced by the kernel itself
@@ -39,7 +40,8 @@ int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float
 // conv9_mfma.hip (9x9, pad 4, Cin % 32 == 0, Cout <= 3: the output convolution)
 bool conv9_mfma_supported(const ConvGeom& g);
 int conv9_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* stream);
-int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
+int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate,
+                     const float* mask_src, int mask_act, int unps_r, void* stream);
 size_t conv9_mfma_wgrad_workspace(const ConvGeom& g);
 int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream);
 

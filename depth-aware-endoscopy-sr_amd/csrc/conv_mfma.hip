@@ -33,6 +33,11 @@ struct ConvMfmaArgs {
     float* y;
     int B, H, W, Cin, Cout;
     int act, ps_r, accumulate;
+    // dgrad only: multiply by act'(mask_src[same index]) (mask_src = the forward conv's INPUT, which is the
+    // activated output of the producing layer) and store through the INVERSE PixelShuffle(unps_r) map, i.e.
+    // write the gradient w.r.t. the producing conv's raw output directly (no separate epilogue-backward pass)
+    const float* mask_src;
+    int mask_act, unps_r;
 };
 
 // CM_TH = tile rows = 2 x waves per workgroup (8 rows / 256 threads, or 16 rows / 512 threads: the 16-row tile
@@ -168,7 +173,13 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
                 float v = acc[m][n][r] + bv;
                 if (a.residual) v += a.residual[pidx];
                 v = dasr_act(v, a.act);
+                if (a.mask_src) v *= dasr_act_grad_from_out(a.mask_src[pidx], a.mask_act);
                 size_t o = pidx;
+                if (a.unps_r > 1) {
+                    const int ur = a.unps_r;
+                    o = ((((size_t)b * (a.H / ur) + gy / ur) * (a.W / ur) + gx / ur) * a.Cout + co) * (ur * ur) +
+                        (gy % ur) * ur + (gx % ur);
+                }
                 if (a.ps_r > 1) {
                     int c = co / rr, i = (co / a.ps_r) % a.ps_r, j = co % a.ps_r;
                     o = (((size_t)b * a.H * a.ps_r + (size_t)gy * a.ps_r + i) * ((size_t)a.W * a.ps_r) +
@@ -216,13 +227,15 @@ static int launch_conv_mfma(ConvMfmaArgs& a, void* stream) {
 
 int conv_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
                   float* y, int act, int ps_r, void* stream) {
-    ConvMfmaArgs a{x, w, bias, residual, y, g.B, g.H, g.W, g.Cin, g.Cout, act, ps_r, 0};
+    ConvMfmaArgs a{x, w, bias, residual, y, g.B, g.H, g.W, g.Cin, g.Cout, act, ps_r, 0, nullptr, 0, 1};
     return launch_conv_mfma<0>(a, stream);
 }
 
 // dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * W[tap][ci][co]: a 3x3 conv of dconv (channels Cout) to Cin
-int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream) {
-    ConvMfmaArgs a{dconv, w, nullptr, nullptr, dx, g.B, g.H, g.W, g.Cout, g.Cin, DASR_ACT_NONE, 1, accumulate};
+int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate,
+                    const float* mask_src, int mask_act, int unps_r, void* stream) {
+    ConvMfmaArgs a{dconv, w, nullptr, nullptr, dx, g.B, g.H, g.W, g.Cout, g.Cin, DASR_ACT_NONE, 1, accumulate,
+                   mask_src, mask_act, unps_r < 1 ? 1 : unps_r};
     return launch_conv_mfma<1>(a, stream);
 }
 bool conv_mfma_dgrad_supported(const ConvGeom& g) {

@@ -82,6 +82,11 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
     needs = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad) or \
         (residual is not None and residual.requires_grad)
     out = Var(y, needs)
+    x.uses += 1
+    if residual is not None:
+        residual.uses += 1
+    if (act != ops.ACT_NONE or ps_r > 1) and residual is None:
+        out.epilogue = (act, ps_r)
     KH, KW, Cin, Cout = w.data.shape[1:]
     wshape = (KH, KW, Cin, Cout)
     B, H, W_, _ = x.data.shape
@@ -100,7 +105,9 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             if bias is not None:
                 accum(bias, db)
             return
-        if act != ops.ACT_NONE or ps_r > 1:
+        if out.grad_is_preact:
+            dconv = dy                       # the (single) consumer's dgrad already applied this epilogue's backward
+        elif act != ops.ACT_NONE or ps_r > 1:
             dconv = ops.conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r)
         else:
             dconv = dy
@@ -111,7 +118,14 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             if bias is not None:
                 accum(bias, db)
         if x.requires_grad:
-            if x.grad is None:
+            if (x.grad is None and x.uses == 1 and x.epilogue is not None and
+                    ops.conv2d_dgrad_act_supported(x.data.shape, w.data, dconv.shape, stride, pad, transposed,
+                                                   x.epilogue[1])):
+                # x = PixelShuffle(act(prev conv)) and this conv is its only consumer: write d(prev conv output)
+                x.grad = ops.conv2d_dgrad_act(dconv, w.data, x.data, x.epilogue[0], x.epilogue[1], stride, pad,
+                                              transposed)
+                x.grad_is_preact = True
+            elif x.grad is None:
                 x.grad = ops.conv2d_dgrad(dconv, w.data, x.data.shape, stride, pad, transposed)
             else:
                 ops.conv2d_dgrad(dconv, w.data, x.data.shape, stride, pad, transposed, out=x.grad)
@@ -123,6 +137,8 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
 
 
 def add(tape, a, b):
+    a.uses += 1
+    b.uses += 1
     out = Var(ops.add(a.data, b.data), a.requires_grad or b.requires_grad)
 
     def bwd():
@@ -138,6 +154,7 @@ def add(tape, a, b):
 
 
 def region_pool(tape, feat, mask):
+    feat.uses += 1
     st, maskr, area = ops.region_pool_fwd(feat.data, mask)
     out = Var(st, feat.requires_grad)
 
@@ -173,6 +190,10 @@ def dynk(tape, st, A_w, A_b, Wg, Wb):
 
 def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu):
     """``mask`` is a MaskPack (float planes + region index + one-hot flag)."""
+    t.uses += 1
+    gb2.uses += 1
+    if residual is not None:
+        residual.uses += 1
     mean, var = ops.instnorm_stats(t.data)
     y = ops.sean_fwd(t.data, mean, var, gb2.data, mask.planes, mask.region, mask.flag, D.data, bias_g.data, bias_b.data,
                      alpha_g.data, alpha_b.data, residual.data if residual is not None else None, relu)

@@ -170,6 +170,25 @@ def conv2d_dgrad(dconv, w, x_shape, stride=1, pad=1, transposed=False, out=None)
     return out
 
 
+def conv2d_dgrad_act_supported(x_shape, w, dconv_shape, stride, pad, transposed, ps_r):
+    B, H, W, Cin = x_shape
+    KH, KW, _, Cout = _wdims(w)
+    _, Ho, Wo, _ = dconv_shape
+    return bool(_lib.get().dasr_conv2d_dgrad_act_supported(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad,
+                                                          int(transposed), ps_r))
+
+
+def conv2d_dgrad_act(dconv, w, x_act, act, ps_r, stride=1, pad=1, transposed=False):
+    """Gradient w.r.t. the PRODUCER conv's raw output: dgrad * act'(x_act), stored un-shuffled."""
+    B, H, W, Cin = x_act.shape
+    KH, KW, _, Cout = _wdims(w)
+    _, Ho, Wo, _ = dconv.shape
+    out = torch.empty((B, H // ps_r, W // ps_r, Cin * ps_r * ps_r), dtype=torch.float32, device=dconv.device)
+    _call("dasr_conv2d_dgrad_act", _p(dconv), _p(w), _p(x_act), _p(out), B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad,
+          int(transposed), act, ps_r)
+    return out
+
+
 def conv2d_wgrad(x, dconv, w_shape, stride=1, pad=1, transposed=False, want_bias=True):
     B, H, W, Cin = x.shape
     KH, KW, _, Cout = w_shape

@@ -11,13 +11,16 @@ from . import ops
 
 class Var:
     """A device tensor plus its gradient slot."""
-    __slots__ = ("data", "grad", "requires_grad", "name")
+    __slots__ = ("data", "grad", "requires_grad", "name", "uses", "epilogue", "grad_is_preact")
 
     def __init__(self, data, requires_grad=False, name=None):
         self.data = data
         self.grad = None
         self.requires_grad = requires_grad
         self.name = name
+        self.uses = 0                # differentiable consumers recorded during the forward
+        self.epilogue = None         # (act, ps_r) when produced by a conv with a fused activation / PixelShuffle
+        self.grad_is_preact = False  # the consumer already applied the epilogue backward (dasr_conv2d_dgrad_act)
 
     @property
     def shape(self):

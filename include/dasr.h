@@ -97,6 +97,17 @@ int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, int 
 /* dx (+)= conv-transpose of dconv with w; accumulate != 0 adds into dx. */
 int dasr_conv2d_dgrad(const float* dconv, const float* w_hwio, float* dx, int accumulate, int B, int H, int W, int Cin,
                       int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int transposed, void* stream);
+/* Data gradient fused with the PRODUCER's epilogue backward.  When the conv input x is the activated (and possibly
+ * pixel-shuffled) output of another convolution - x = PixelShuffle_r(act(prev)) - and this conv is its only
+ * consumer, the gradient w.r.t. prev is  dprev = unshuffle_r( dgrad(dconv) * act'(x) ):  the activation mask is
+ * applied in the dgrad epilogue and the store goes through the inverse PixelShuffle index map, so the producer
+ * needs no dasr_conv2d_epilogue_bwd pass.  x_act = this conv's saved input [B,H,W,Cin];
+ * dprev [B, H/r, W/r, Cin*r*r].  dasr_conv2d_dgrad_act_supported() tells whether a kernel exists. */
+int dasr_conv2d_dgrad_act_supported(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                    int pad, int transposed, int ps_r);
+int dasr_conv2d_dgrad_act(const float* dconv, const float* w_hwio, const float* x_act, float* dprev, int B, int H, int W,
+                          int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int transposed,
+                          int act, int ps_r, void* stream);
 /* dw_hwio = sum_pixels x (x) dconv ; dbias[co] = sum dconv (dbias may be NULL).
  * workspace: dasr_conv2d_wgrad_workspace() bytes. */
 size_t dasr_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
