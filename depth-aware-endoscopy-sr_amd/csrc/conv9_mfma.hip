@@ -129,6 +129,7 @@ __device__ __forceinline__ void c9_stage_dy(const Conv9Args& a, float* sDy, int 
     }
 }
 
+template <bool UNMASK>
 __global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
     DASR_DYN_SMEM(smem);
     float* sDy = (float*)smem;                       // [16][DYW]
@@ -177,11 +178,13 @@ __global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
             if (gx >= a.W) continue;
             size_t o = (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + n0 + li;
             float v = acc[t][g];
-            if (a.mask_src) v *= dasr_act_grad_from_out(a.mask_src[o], a.mask_act);
-            if (a.unps_r > 1) {
-                const int ur = a.unps_r;
-                o = ((((size_t)b * (a.H / ur) + gy / ur) * (a.W / ur) + gx / ur) * a.Cin + n0 + li) * (ur * ur) +
-                    (gy % ur) * ur + (gx % ur);
+            if (UNMASK) {
+                v *= dasr_act_grad_from_out(a.mask_src[o], a.mask_act);
+                if (a.unps_r > 1) {
+                    const int ur = a.unps_r;
+                    o = ((((size_t)b * (a.H / ur) + gy / ur) * (a.W / ur) + gx / ur) * a.Cin + n0 + li) * (ur * ur) +
+                        (gy % ur) * ur + (gx % ur);
+                }
             }
             if (a.accumulate) v += a.out[o];
             a.out[o] = v;
@@ -275,7 +278,11 @@ int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, floa
                 mask_src, mask_act, unps_r < 1 ? 1 : unps_r};
     int tiles = ((g.W + C9_TQ - 1) / C9_TQ) * ((g.H + C9_TH - 1) / C9_TH);
     size_t lds = sizeof(float) * (size_t)((C9_TH + 8) * C9_DYW + 9 * 28 * 32);
-    DASR_LAUNCH(k_conv9x9_dgrad_mfma, dim3(tiles, g.B, g.Cin / 32), dim3(256), lds, stream, a);
+    if (mask_src) {
+        DASR_LAUNCH((k_conv9x9_dgrad_mfma<true>), dim3(tiles, g.B, g.Cin / 32), dim3(256), lds, stream, a);
+    } else {
+        DASR_LAUNCH((k_conv9x9_dgrad_mfma<false>), dim3(tiles, g.B, g.Cin / 32), dim3(256), lds, stream, a);
+    }
     DASR_RETURN_LAUNCH_STATUS();
 }
 static void conv9_wgrad_plan(const ConvGeom& g, int& ntiles, int& P) {

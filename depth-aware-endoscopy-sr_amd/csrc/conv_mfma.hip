@@ -43,7 +43,7 @@ struct ConvMfmaArgs {
 // CM_TH = tile rows = 2 x waves per workgroup (8 rows / 256 threads, or 16 rows / 512 threads: the 16-row tile
 // stages each weight slice once for twice the pixels - weights are ~60 % of the staged bytes - and still keeps
 // two waves per SIMD with a single workgroup per CU).
-template <int NT, int WMODE, int CM_TH>
+template <int NT, int WMODE, int CM_TH, bool UNMASK>
 __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
     DASR_DYN_SMEM(smem);
     constexpr int CM_HALO_H = CM_TH + 2;
@@ -173,12 +173,14 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
                 float v = acc[m][n][r] + bv;
                 if (a.residual) v += a.residual[pidx];
                 v = dasr_act(v, a.act);
-                if (a.mask_src) v *= dasr_act_grad_from_out(a.mask_src[pidx], a.mask_act);
                 size_t o = pidx;
-                if (a.unps_r > 1) {
-                    const int ur = a.unps_r;
-                    o = ((((size_t)b * (a.H / ur) + gy / ur) * (a.W / ur) + gx / ur) * a.Cout + co) * (ur * ur) +
-                        (gy % ur) * ur + (gx % ur);
+                if (UNMASK) {            // dgrad fused with the producer's activation backward (+ inverse PixelShuffle)
+                    v *= dasr_act_grad_from_out(a.mask_src[pidx], a.mask_act);
+                    if (a.unps_r > 1) {
+                        const int ur = a.unps_r;
+                        o = ((((size_t)b * (a.H / ur) + gy / ur) * (a.W / ur) + gx / ur) * a.Cout + co) * (ur * ur) +
+                            (gy % ur) * ur + (gx % ur);
+                    }
                 }
                 if (a.ps_r > 1) {
                     int c = co / rr, i = (co / a.ps_r) % a.ps_r, j = co % a.ps_r;
@@ -205,23 +207,20 @@ template <int WMODE>
 static int launch_conv_mfma(ConvMfmaArgs& a, void* stream) {
     const int TH = (a.H % 16) == 0 ? 16 : 8;
     int tiles = ((a.W + CM_TW - 1) / CM_TW) * ((a.H + TH - 1) / TH);
-    if ((a.Cout % 64) == 0) {
-        if (TH == 16) {
-            DASR_LAUNCH((k_conv3x3_mfma<2, WMODE, 16>), dim3(tiles, a.B, a.Cout / 64), dim3(512), conv_mfma_lds(2, 16),
-                        stream, a);
-        } else {
-            DASR_LAUNCH((k_conv3x3_mfma<2, WMODE, 8>), dim3(tiles, a.B, a.Cout / 64), dim3(256), conv_mfma_lds(2, 8),
-                        stream, a);
-        }
+    const bool nt2 = (a.Cout % 64) == 0;
+    const dim3 grid(tiles, a.B, a.Cout / (nt2 ? 64 : 32));
+    const dim3 block(32 * TH);
+    const size_t lds = conv_mfma_lds(nt2 ? 2 : 1, TH);
+    const bool um = a.mask_src != nullptr;
+#define CM_GO(NTv, THv, UMv) DASR_LAUNCH((k_conv3x3_mfma<NTv, WMODE, THv, UMv>), grid, block, lds, stream, a)
+    if (!um) {
+        if (nt2) { if (TH == 16) CM_GO(2, 16, false); else CM_GO(2, 8, false); }
+        else     { if (TH == 16) CM_GO(1, 16, false); else CM_GO(1, 8, false); }
     } else {
-        if (TH == 16) {
-            DASR_LAUNCH((k_conv3x3_mfma<1, WMODE, 16>), dim3(tiles, a.B, a.Cout / 32), dim3(512), conv_mfma_lds(1, 16),
-                        stream, a);
-        } else {
-            DASR_LAUNCH((k_conv3x3_mfma<1, WMODE, 8>), dim3(tiles, a.B, a.Cout / 32), dim3(256), conv_mfma_lds(1, 8),
-                        stream, a);
-        }
+        if (nt2) { if (TH == 16) CM_GO(2, 16, true); else CM_GO(2, 8, true); }
+        else     { if (TH == 16) CM_GO(1, 16, true); else CM_GO(1, 8, true); }
     }
+#undef CM_GO
     DASR_RETURN_LAUNCH_STATUS();
 }
 

@@ -118,7 +118,9 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             if bias is not None:
                 accum(bias, db)
         if x.requires_grad:
-            if (x.grad is None and x.uses == 1 and x.epilogue is not None and
+            # (measured on MI355X: with a PixelShuffle in between, the scattered un-shuffle stores cost more than the
+            #  epilogue-backward pass they save, so only the activation-only case is fused)
+            if (x.grad is None and x.uses == 1 and x.epilogue is not None and x.epilogue[1] == 1 and
                     ops.conv2d_dgrad_act_supported(x.data.shape, w.data, dconv.shape, stride, pad, transposed,
                                                    x.epilogue[1])):
                 # x = PixelShuffle(act(prev conv)) and this conv is its only consumer: write d(prev conv output)

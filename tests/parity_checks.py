@@ -370,3 +370,23 @@ def check_fused_loss(device):
         assert abs(l_dyn.item() - l_dyn_o.item()) <= 2e-5 * max(1, abs(l_dyn_o.item()))
         assert rel_max(sr_d.grad, sr_o.grad) <= 2e-5
         assert rel_max(w_d.grad, w_o.grad) <= 2e-5
+
+
+def check_dgrad_act(device):
+    """dasr_conv2d_dgrad_act == dgrad, times act'(x), through the inverse PixelShuffle map (3x3 MFMA and 9x9 paths)."""
+    gen = torch.Generator().manual_seed(5)
+    for (cin, cout, k, pad, H, W, r, act) in [(32, 64, 3, 1, 8, 34, 1, ops.ACT_RELU), (32, 32, 3, 1, 16, 36, 2, ops.ACT_LRELU),
+                                              (64, 32, 3, 1, 6, 33, 3, ops.ACT_LRELU), (32, 3, 9, 4, 10, 66, 2, ops.ACT_LRELU),
+                                              (32, 3, 9, 4, 12, 30, 1, ops.ACT_RELU)]:
+        B = 2
+        x_act = torch.randn(B, H, W, cin, generator=gen).to(device)
+        w = ops.pack_hwio((torch.randn(k, k, cin, cout, generator=gen) * 0.1).to(device))
+        dconv = torch.randn(B, H, W, cout, generator=gen).to(device)
+        assert ops.conv2d_dgrad_act_supported(x_act.shape, w, dconv.shape, 1, pad, False, r)
+        got = ops.conv2d_dgrad_act(dconv, w, x_act, act, r, 1, pad, False)
+        ref = ops.conv2d_dgrad(dconv, w, x_act.shape, 1, pad, False)
+        slope = 0.0 if act == ops.ACT_RELU else 0.2
+        ref = ref * torch.where(x_act > 0, torch.ones_like(x_act), torch.full_like(x_act, slope))
+        ref = nhwc(F.pixel_unshuffle(nchw(ref.cpu()), r)) if r > 1 else ref.cpu()
+        assert got.shape == ref.shape
+        assert rel_max(got, ref) <= 1e-6, (cin, cout, k, r)

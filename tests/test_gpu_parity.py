@@ -40,6 +40,10 @@ def test_blocks():
     pc.check_blocks("cuda")
 
 
+def test_dgrad_act():
+    pc.check_dgrad_act("cuda")
+
+
 def test_fused_loss():
     pc.check_fused_loss("cuda")
 

@@ -28,6 +28,10 @@ def test_blocks(emu):
     pc.check_blocks("cpu")
 
 
+def test_dgrad_act(emu):
+    pc.check_dgrad_act("cpu")
+
+
 def test_fused_loss(emu):
     pc.check_fused_loss("cpu")
 
