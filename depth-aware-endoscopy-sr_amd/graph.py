@@ -14,6 +14,14 @@ from . import ops
 from .tape import Tape, Var, accum
 
 
+# dasr_conv2d_dgrad_act (the producer's activation / PixelShuffle backward applied in the consumer's dgrad epilogue)
+# is OFF by default.  Measured on MI355X at the x8 bench shapes it removes the epilogue-backward passes (26 -> 6 ms
+# per 4 steps) but the masked epilogue's extra 4-byte loads and the scattered un-shuffle stores are not hidden
+# under matrix work: the 9x9 dgrad went 3.6 -> 6.2 ms and the 128->128 dgrad 0.82 -> 1.14 ms, a net loss of 4-10 %
+# of the step.  Kept as a tested entry point for shapes where the producer tensor is small.
+FUSE_DGRAD_ACT = False
+
+
 # ---------------------------------------------------------------------------------------------
 # recorded primitives
 # ---------------------------------------------------------------------------------------------
@@ -118,9 +126,7 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             if bias is not None:
                 accum(bias, db)
         if x.requires_grad:
-            # (measured on MI355X: with a PixelShuffle in between, the scattered un-shuffle stores cost more than the
-            #  epilogue-backward pass they save, so only the activation-only case is fused)
-            if (x.grad is None and x.uses == 1 and x.epilogue is not None and x.epilogue[1] == 1 and
+            if (FUSE_DGRAD_ACT and x.grad is None and x.uses == 1 and x.epilogue is not None and
                     ops.conv2d_dgrad_act_supported(x.data.shape, w.data, dconv.shape, stride, pad, transposed,
                                                    x.epilogue[1])):
                 # x = PixelShuffle(act(prev conv)) and this conv is its only consumer: write d(prev conv output)
