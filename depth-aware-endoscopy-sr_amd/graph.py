@@ -273,6 +273,10 @@ def sean(tape, P, pre, t, depth_map, mask, st, residual, relu, consts):
     B, H, W, C = t.data.shape
     assert st.data.shape[1] == mask.shape[1], "depth matrix regions != mask channels"   # normalization.py:54
     assert st.data.shape[2] == P[pre + ".mlp_gamma_s.weight"].data.shape[1], "len_latent != depth matrix width"
+    if P[pre + ".A_i_j.weight"].data.shape[0] != st.data.shape[1]:
+        # the reference fails here inside nn.Conv2d (A_i_j expects depthRangeNum channels): same error class
+        raise RuntimeError("SEAN.A_i_j expects %d depth regions, got %d mask channels"
+                           % (P[pre + ".A_i_j.weight"].data.shape[0], st.data.shape[1]))
     # gamma2 / beta2: a function of the depth map only
     w_m = pack(tape, P[pre + ".mlp_mask.0.weight"])
     actv = conv(tape, depth_map, w_m, P[pre + ".mlp_mask.0.bias"], act=ops.ACT_RELU)

@@ -390,3 +390,142 @@ def check_dgrad_act(device):
         ref = nhwc(F.pixel_unshuffle(nchw(ref.cpu()), r)) if r > 1 else ref.cpu()
         assert got.shape == ref.shape
         assert rel_max(got, ref) <= 1e-6, (cin, cout, k, r)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# edge cases of the module boundary
+# ------------------------------------------------------------------------------------------------------------
+def _oracle_sd(net):
+    return {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+
+
+def _compare_with_oracle(net, cfg, lq, dm, mk, device, fwd_tol=2e-4, grad_tol=5e-3):
+    sd = _oracle_sd(net)
+    sr = net(lq.to(device), dm.to(device), mk.to(device))
+    ref = O.depthnet_forward(sd, cfg, lq, dm, mk)
+    err = (sr.detach().cpu() - ref.detach()).abs().max().item()
+    assert err <= fwd_tol, err
+    wgt = torch.cos(torch.arange(sr.numel(), dtype=torch.float32) * 0.013).reshape(sr.shape)
+    (sr * wgt.to(device)).sum().backward()
+    (ref * wgt).sum().backward()
+    num = den = 0.0
+    for k, p in net.named_parameters():
+        if sd[k].grad is None:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        if any(s in k for s in ZERO_GRAD_KEYS):
+            continue
+        num += (p.grad.detach().cpu().double() - sd[k].grad.double()).pow(2).sum().item()
+        den += sd[k].grad.double().pow(2).sum().item()
+    rel = math.sqrt(num / max(den, 1e-300))
+    assert rel <= grad_tol, rel
+    return err, rel
+
+
+def check_soft_masks_whole_net(device):
+    """Arbitrary float masks (not one-hot): the general kernels carry the whole net."""
+    case = dict(scale=2, which=[0, 1, 2, 3], L=16, nb=4, B=1, H=8, W=12)
+    net, cfg = build_net(case, device)
+    lq, gt, dm, mk = synth.closed_form_batch(2, 1, 8, 12, 2)
+    soft = 0.7 * mk + 0.3 * synth.hash_uniform(mk.numel(), "soft").reshape(mk.shape).float()
+    return _compare_with_oracle(net, cfg, lq, dm, soft, device)
+
+
+def check_constant_alpha_and_mask_resize(device):
+    """use_trainable_params=False (constant blend weights) and a depth map / masks at HALF the LR resolution:
+    F.interpolate(nearest) inside SEAN (normalization.py:58-59) and the bilinear+threshold resize of the region
+    pooling (sftmd_arch.py:715-718)."""
+    cfg = O.make_cfg(which_ResBlk_depth=[0, 1], nb=4, scale=4, depth_latent_ch=16, use_trainable_params=False,
+                     norm_gamma=0.3, norm_beta=0.6)
+    net = DepthNet(which_ResBlk_depth=[0, 1], nb=4, scale=4, depth_latent_ch=16, use_trainable_params=False,
+                   norm_gamma=0.3, norm_beta=0.6)
+    synth.closed_form_fill_(net.state_dict().items())
+    net = net.to(device)
+    assert not any("alpha" in k for k in net.state_dict())
+    lq, _, _, _ = synth.closed_form_batch(0, 2, 12, 16, 4)
+    _, _, dm, mk = synth.closed_form_batch(0, 2, 6, 8, 4)          # half-resolution depth inputs
+    return _compare_with_oracle(net, cfg, lq, dm, mk, device)
+
+
+def check_batch_independence_and_determinism(device):
+    """Instance norm is per sample: a frame's output must not depend on its batch mates; repeated runs are bitwise
+    identical in the forward (no atomics on the forward path)."""
+    case = dict(scale=8, which=[0, 1], L=16, nb=4, B=3, H=8, W=12)
+    net, cfg = build_net(case, device)
+    lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, 3, 8, 12, 8)]
+    with torch.no_grad():
+        full = net(lq, dm, mk)
+        again = net(lq, dm, mk)
+        solo = net(lq[1:2].contiguous(), dm[1:2].contiguous(), mk[1:2].contiguous())
+    assert torch.equal(full, again)
+    assert torch.equal(full[1:2], solo)
+    assert full.min().item() >= 0.0 and full.max().item() <= 1.0          # torch.clamp(out, 0, 1)
+    assert tuple(full.shape) == (3, 3, 64, 96)
+
+
+def check_state_dict_roundtrip(device):
+    """state_dict keys == the reference's (dumped in tests/golden/state_dict_keys.json); strict load works."""
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    for scale, which, L in ((8, list(range(14)), 256), (4, list(range(14)), 256), (2, list(range(16)), 32)):
+        net = DepthNet(which_ResBlk_depth=which, nb=16, scale=scale, depth_latent_ch=L)
+        ref = keys["x%d" % scale]
+        sd = net.state_dict()
+        assert [k for k, _ in ref] == list(sd.keys())
+        assert [tuple(s) for _, s in ref] == [tuple(v.shape) for v in sd.values()]
+        assert sum(p.numel() for p in net.parameters()) == keys["x%d_nparams" % scale]
+        other = DepthNet(which_ResBlk_depth=which, nb=16, scale=scale, depth_latent_ch=L)
+        other.load_state_dict(sd, strict=True)
+    for bad in (dict(norm_type="instance"), dict(ablate_depth_block=True), dict(ablate_depth_matrix=True)):
+        try:
+            DepthNet(which_ResBlk_depth=[0], nb=4, scale=2, **bad)
+            raise AssertionError("expected NotImplementedError")
+        except NotImplementedError:
+            pass
+
+
+def check_reference_assertion(device):
+    """The reference asserts len_latent == st.size(2) and st.size(1) == depthMask.size(1) (normalization.py:54)."""
+    case = dict(scale=2, which=[0, 1, 2, 3], L=16, nb=4, B=1, H=8, W=12)
+    net, cfg = build_net(case, device)
+    lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, 1, 8, 12, 2, num_masks=7)]
+    try:
+        net(lq, dm, mk)          # 7 mask planes against a net built for 10 regions
+        raise RuntimeError("expected an AssertionError / shape error")
+    except (AssertionError, RuntimeError) as e:
+        assert "expected an" not in str(e)
+
+
+def check_full_size_x8(device):
+    """BASELINE.json's full shapes (x8 net, nb=16, L=256, 128x160 LR -> 1024x1280) on one frame against the CPU
+    oracle: forward error, PSNR agreement (north_star: within 1e-3 dB) and gradients of a linear functional."""
+    cfg = O.make_cfg()
+    net = DepthNet(which_ResBlk_depth=list(range(14)), nb=16, scale=8, depth_latent_ch=256)
+    synth.closed_form_fill_(net.state_dict().items())
+    net = net.to(device)
+    lq, gt, dm, mk = synth.seeded_batch(0, 1, 128, 160, 8)
+    sd = _oracle_sd(net)
+    sr = net(lq.to(device), dm.to(device), mk.to(device))
+    ref = O.depthnet_forward(sd, cfg, lq, dm, mk)
+    assert tuple(sr.shape) == (1, 3, 1024, 1280)
+    err = (sr.detach().cpu() - ref.detach()).abs().max().item()
+    dpsnr = abs(O.psnr_255(sr.detach().cpu(), gt) - O.psnr_255(ref.detach(), gt))
+    psnr_vs_ref = O.psnr_255(sr.detach().cpu(), ref.detach())
+    assert err <= 5e-4, err
+    assert dpsnr <= 1e-3, dpsnr
+    assert psnr_vs_ref >= 100.0, psnr_vs_ref
+    wgt = torch.cos(torch.arange(sr.numel(), dtype=torch.float32) * 0.013).reshape(sr.shape)
+    (sr * wgt.to(device)).sum().backward()
+    (ref * wgt).sum().backward()
+    num = den = 0.0
+    for k, p in net.named_parameters():
+        if sd[k].grad is None:
+            assert p.grad is None, k
+            continue
+        if any(s in k for s in ZERO_GRAD_KEYS):
+            continue
+        num += (p.grad.detach().cpu().double() - sd[k].grad.double()).pow(2).sum().item()
+        den += sd[k].grad.double().pow(2).sum().item()
+    rel = math.sqrt(num / den)
+    assert rel <= 5e-3, rel
+    return dict(max_err=err, dpsnr=dpsnr, psnr_vs_ref=psnr_vs_ref, grad_rel_l2=rel)

@@ -59,6 +59,26 @@ def test_depthnet(case):
     print(case["name"], r)
 
 
+def test_soft_masks_whole_net():
+    print(pc.check_soft_masks_whole_net("cuda"))
+
+
+def test_constant_alpha_and_mask_resize():
+    print(pc.check_constant_alpha_and_mask_resize("cuda"))
+
+
+def test_batch_independence_and_determinism():
+    pc.check_batch_independence_and_determinism("cuda")
+
+
+def test_reference_assertion():
+    pc.check_reference_assertion("cuda")
+
+
+def test_full_size_x8_vs_oracle():
+    print(pc.check_full_size_x8("cuda"))
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()

@@ -45,3 +45,23 @@ def test_depthnet(emu, case):
     tol = 0.2 if case["name"].endswith("odd") else 2e-3   # 'odd' case: a ReLU flip makes even the fp64 oracle move
     r = pc.check_depthnet_case(case, "cpu", lin_tol=tol, loss_tol=0.3)
     print(case["name"], r)
+
+
+def test_soft_masks_whole_net(emu):
+    print(pc.check_soft_masks_whole_net("cpu"))
+
+
+def test_constant_alpha_and_mask_resize(emu):
+    print(pc.check_constant_alpha_and_mask_resize("cpu"))
+
+
+def test_batch_independence_and_determinism(emu):
+    pc.check_batch_independence_and_determinism("cpu")
+
+
+def test_state_dict_roundtrip():
+    pc.check_state_dict_roundtrip("cpu")
+
+
+def test_reference_assertion(emu):
+    pc.check_reference_assertion("cpu")
