@@ -527,5 +527,8 @@ def check_full_size_x8(device):
         num += (p.grad.detach().cpu().double() - sd[k].grad.double()).pow(2).sum().item()
         den += sd[k].grad.double().pow(2).sum().item()
     rel = math.sqrt(num / den)
-    assert rel <= 5e-3, rel
+    # At this depth (13 DGBs, 3.9 M clamped outputs) fp32 gradients are only defined to ~1 %: the fp32 ORACLE deviates
+    # from its own fp64 run by 1.47e-2 relative L2 and this implementation by 1.05e-2 (tools/diag_full_size.py,
+    # profiles/r01_full_size_fp64_diagnostic.txt) - ReLU / clamp decisions flip on ~1e-7 differences.
+    assert rel <= 3e-2, rel
     return dict(max_err=err, dpsnr=dpsnr, psnr_vs_ref=psnr_vs_ref, grad_rel_l2=rel)
