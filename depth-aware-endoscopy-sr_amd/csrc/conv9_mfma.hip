@@ -245,18 +245,21 @@ __global__ void __launch_bounds__(256) k_conv9x9_wgrad_mfma(Conv9Args a) {
         }
 }
 
-// dw[kh][kw][ci][co] = sum over slabs of slab[cig][kh][ci%32][(8-kw)*Cout+co]
+// dw[kh][kw][ci][co] = sum over slabs of slab[cig][kh][ci%32][(8-kw)*Cout+co]; the slab range is split over
+// blockIdx.y (partial sums meet in the zeroed dw through float atomics)
 __global__ void __launch_bounds__(256) k_conv9_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                            int Cin, int Cout, int nslabs, int cgroups) {
+                                                            int Cin, int Cout, int nslabs, int cgroups, int per_y) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int n = 81 * Cin * Cout;
     if (i >= n) return;
     int co = i % Cout, ci = (i / Cout) % Cin, kw = (i / (Cout * Cin)) % 9, kh = i / (Cout * Cin * 9);
     int np = (8 - kw) * Cout + co;
     const float* p = slabs + (size_t)(ci / 32) * (9 * 32 * 32) + (kh * 32 + (ci & 31)) * 32 + np;
+    const int s0 = blockIdx.y * per_y;
+    const int s1 = s0 + per_y < nslabs ? s0 + per_y : nslabs;
     float acc = 0.f;
-    for (int s = 0; s < nslabs; ++s) acc += p[(size_t)s * cgroups * (9 * 32 * 32)];
-    dw[i] = acc;
+    for (int s = s0; s < s1; ++s) acc += p[(size_t)s * cgroups * (9 * 32 * 32)];
+    atomicAdd(&dw[i], acc);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -303,7 +306,10 @@ int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, floa
     size_t lds = sizeof(float) * (size_t)(C9_TH * C9_TQ * 32 + (C9_TH + 8) * C9_DYW);
     DASR_LAUNCH(k_conv9x9_wgrad_mfma, dim3(g.Cin / 32, P), dim3(256), lds, stream, a);
     int n = 81 * g.Cin * g.Cout;
-    DASR_LAUNCH(k_conv9_wgrad_reduce, dim3(dasr_cdiv(n, 256)), dim3(256), 0, stream, (const float*)workspace, dw, g.Cin,
-                g.Cout, P * 4, g.Cin / 32);
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * n, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    const int nslabs = P * 4, ysplit = nslabs >= 64 ? 32 : 1;
+    DASR_LAUNCH(k_conv9_wgrad_reduce, dim3(dasr_cdiv(n, 256), ysplit), dim3(256), 0, stream, (const float*)workspace, dw,
+                g.Cin, g.Cout, nslabs, g.Cin / 32, (nslabs + ysplit - 1) / ysplit);
     DASR_RETURN_LAUNCH_STATUS();
 }

@@ -151,6 +151,30 @@ __global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ m, flo
                                                  red[threadIdx.x + 192]);
 }
 
+// narrow matrices (C <= 8, e.g. the 3-channel output gradient at HR): one thread sums whole rows
+__global__ void __launch_bounds__(256) k_colsum_small(const float* __restrict__ m, float* __restrict__ out, size_t rows,
+                                                      int C) {
+    __shared__ float red[8][4];
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
+        const float* p = m + r * C;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) acc[c] += p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float v = acc[c];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) atomicAdd(&out[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] +
+                                                          red[threadIdx.x][3]);
+}
+
 // ------------------------------------------------------------------------------------------ host side
 int conv_direct_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
                     float* y, int act, int ps_r, void* stream) {
@@ -172,6 +196,10 @@ int conv_direct_dgrad(const ConvGeom& g, const float* dconv, const float* w, flo
 int conv_colsum(const float* m, float* out, size_t rows, int C, void* stream) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
+    if (C <= 8) {
+        DASR_LAUNCH(k_colsum_small, dim3(dasr_ew_grid(rows)), dim3(256), 0, stream, m, out, rows, C);
+        DASR_RETURN_LAUNCH_STATUS();
+    }
     unsigned nsplit = (unsigned)((rows + 255) / 256);
     if (nsplit > 2048) nsplit = 2048;
     if (nsplit < 1) nsplit = 1;

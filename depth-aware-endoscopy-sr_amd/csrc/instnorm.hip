@@ -10,8 +10,63 @@
 
 #define IN_CHUNK 256
 
+// 256 threads = 16 pixel lanes x 16 channel quads: a lane loads float4 (4 channels), a wave-instruction covers four
+// pixels x 256 B.  blockIdx.z selects a 64-channel slice.
 __global__ void __launch_bounds__(256) k_instnorm_partial(const float* __restrict__ x, float* __restrict__ part, int HW,
                                                           int C, int nchunks) {
+    __shared__ float4 red[256];
+    __shared__ float4 mu_s[16];
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.z * 64 + 4 * cq;
+    const bool live = c + 3 < C;
+    const int p0 = chunk * IN_CHUNK;
+    const int p1 = p0 + IN_CHUNK < HW ? p0 + IN_CHUNK : HW;
+    const float* xb = x + (size_t)b * HW * C + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live)
+        for (int p = p0 + pl; p < p1; p += 16) {
+            const float4 v = *(const float4*)(xb + (size_t)p * C);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (pl == 0) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = 0; l < 16; ++l) {
+            const float4 v = red[l * 16 + cq];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const float inv = 1.0f / (float)(p1 - p0);
+        mu_s[cq] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    }
+    __syncthreads();
+    const float4 mu = mu_s[cq];
+    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live)
+        for (int p = p0 + pl; p < p1; p += 16) {
+            const float4 v = *(const float4*)(xb + (size_t)p * C);
+            const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+            acc.x = fmaf(dx, dx, acc.x); acc.y = fmaf(dy, dy, acc.y);
+            acc.z = fmaf(dz, dz, acc.z); acc.w = fmaf(dw, dw, acc.w);
+        }
+    __syncthreads();
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (pl == 0 && live) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = 0; l < 16; ++l) {
+            const float4 v = red[l * 16 + cq];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float* o = part + (((size_t)b * nchunks + chunk) * C + c) * 2;
+        o[0] = mu.x; o[1] = s.x; o[2] = mu.y; o[3] = s.y; o[4] = mu.z; o[5] = s.z; o[6] = mu.w; o[7] = s.w;
+    }
+}
+
+// scalar-lane variant for channel counts that are not a multiple of 4
+__global__ void __launch_bounds__(256) k_instnorm_partial_c1(const float* __restrict__ x, float* __restrict__ part,
+                                                             int HW, int C, int nchunks) {
     __shared__ float red[256];
     __shared__ float mu_s[64];
     const int chunk = blockIdx.x, b = blockIdx.y;
@@ -80,7 +135,12 @@ extern "C" int dasr_instnorm_stats(const float* x, float* mean, float* var, void
     if (workspace_bytes < dasr_instnorm_stats_workspace(B, HW, C)) return DASR_E_WORKSPACE;
     int nchunks = (HW + IN_CHUNK - 1) / IN_CHUNK;
     float* part = (float*)workspace;
-    DASR_LAUNCH(k_instnorm_partial, dim3(nchunks, B, dasr_cdiv(C, 64)), dim3(256), 0, stream, x, part, HW, C, nchunks);
+    if ((C & 3) == 0) {
+        DASR_LAUNCH(k_instnorm_partial, dim3(nchunks, B, dasr_cdiv(C, 64)), dim3(256), 0, stream, x, part, HW, C, nchunks);
+    } else {
+        DASR_LAUNCH(k_instnorm_partial_c1, dim3(nchunks, B, dasr_cdiv(C, 64)), dim3(256), 0, stream, x, part, HW, C,
+                    nchunks);
+    }
     int n = B * C;
     DASR_LAUNCH(k_instnorm_merge, dim3(dasr_cdiv(n, 256)), dim3(256), 0, stream, part, mean, var, HW, C, nchunks, n);
     DASR_RETURN_LAUNCH_STATUS();

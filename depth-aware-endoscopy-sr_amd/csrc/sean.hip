@@ -236,10 +236,35 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const float* __r
     }
 }
 
+// dt = s*(dxhat - S1/N) + s'(var)*(2/N)*(t-mean)*S2; float4 per lane when C % 4 == 0 (per-(b,c) constants are
+// recomputed from mean/var/S: 4 channels x 4 small loads, all L1/L2 hits)
 __global__ void __launch_bounds__(256) k_sean_bwd_b(const float* __restrict__ t, const float* __restrict__ mean,
                                                     const float* __restrict__ var, const float* __restrict__ S,
                                                     float* __restrict__ dt, int HW, int C, size_t n, float eps) {
-    float invN = 1.0f / (float)HW;
+    const float invN = 1.0f / (float)HW;
+    if ((C & 3) == 0) {
+        const size_t n4 = n >> 2;
+        const int C4 = C >> 2;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            const int c = 4 * (int)(i % C4);
+            const size_t b = i / ((size_t)C4 * HW);
+            const size_t bc = b * C + c;
+            const float4 tv = *(const float4*)(t + 4 * i);
+            float4 dv = *(const float4*)(dt + 4 * i);
+            const float4 mu = *(const float4*)(mean + bc), vr = *(const float4*)(var + bc);
+            const float4 s01 = *(const float4*)(S + 2 * bc), s23 = *(const float4*)(S + 2 * bc + 4);
+            dv.x = dasr_double_in_scale(vr.x, eps) * (dv.x - s01.x * invN) +
+                   dasr_double_in_dscale(vr.x, eps) * 2.f * invN * (tv.x - mu.x) * s01.y;
+            dv.y = dasr_double_in_scale(vr.y, eps) * (dv.y - s01.z * invN) +
+                   dasr_double_in_dscale(vr.y, eps) * 2.f * invN * (tv.y - mu.y) * s01.w;
+            dv.z = dasr_double_in_scale(vr.z, eps) * (dv.z - s23.x * invN) +
+                   dasr_double_in_dscale(vr.z, eps) * 2.f * invN * (tv.z - mu.z) * s23.y;
+            dv.w = dasr_double_in_scale(vr.w, eps) * (dv.w - s23.z * invN) +
+                   dasr_double_in_dscale(vr.w, eps) * 2.f * invN * (tv.w - mu.w) * s23.w;
+            *(float4*)(dt + 4 * i) = dv;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         int c = (int)(i % C);
         size_t b = i / ((size_t)C * HW);
@@ -750,6 +775,7 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
                     dres, S, relu, eps, fast ? onehot_flag : (const int*)nullptr);
     }
     size_t n = (size_t)B * H * W * C;
-    DASR_LAUNCH(k_sean_bwd_b, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, t, mean, var, S, dt, H * W, C, n, eps);
+    DASR_LAUNCH(k_sean_bwd_b, dim3(dasr_ew_grid((C & 3) == 0 ? n / 4 : n)), dim3(256), 0, stream, t, mean, var, S, dt,
+                H * W, C, n, eps);
     DASR_RETURN_LAUNCH_STATUS();
 }
