@@ -10,6 +10,8 @@ into convolution epilogues.
 """
 import math
 
+import torch
+
 from . import ops
 from .tape import Tape, Var, accum
 
@@ -20,6 +22,17 @@ from .tape import Tape, Var, accum
 # under matrix work: the 9x9 dgrad went 3.6 -> 6.2 ms and the 128->128 dgrad 0.82 -> 1.14 ms, a net loss of 4-10 %
 # of the step.  Kept as a tested entry point for shapes where the producer tensor is small.
 FUSE_DGRAD_ACT = False
+
+# Run the depth-map branch of the SEANs on a side HIP stream (forward and backward).
+SIDE_STREAM = True
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -105,6 +118,9 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             return
         dy = out.grad
         out.grad = None
+        if out.grad_event is not None:       # the gradient was produced on another stream
+            torch.cuda.current_stream().wait_event(out.grad_event)
+            dy.record_stream(torch.cuda.current_stream())
         if not x.requires_grad and residual is None and ps_r == 1 and act != ops.ACT_NONE:
             # leaf layer (the depth-map branch): activation backward fused into the weight gradient
             dw, db = ops.conv2d_wgrad_act(x.data, dy, y, wshape, act, stride, pad, transposed,
@@ -202,6 +218,9 @@ def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, 
     gb2.uses += 1
     if residual is not None:
         residual.uses += 1
+    if gb2.event is not None:                # gamma2/beta2 were computed on the side stream
+        torch.cuda.current_stream().wait_event(gb2.event)
+        gb2.data.record_stream(torch.cuda.current_stream())
     mean, var = ops.instnorm_stats(t.data)
     y = ops.sean_fwd(t.data, mean, var, gb2.data, mask.planes, mask.region, mask.flag, D.data, bias_g.data, bias_b.data,
                      alpha_g.data, alpha_b.data, residual.data if residual is not None else None, relu)
@@ -217,6 +236,8 @@ def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, 
         out.grad = None
         accum(t, dt)
         accum(gb2, dgb2)
+        if gb2.event is not None:
+            gb2.grad_event = torch.cuda.current_stream().record_event()
         accum(D, dD)
         accum(bias_g, dbg)
         accum(bias_b, dbb)
@@ -268,7 +289,17 @@ def block_plan(cfg):
     return plan
 
 
-def sean(tape, P, pre, t, depth_map, mask, st, residual, relu, consts):
+def sean_depth_branch(tape, P, pre, depth_map):
+    """gamma2 | beta2 of one SEAN (normalization.py:61,73-74): a function of the depth map and parameters only, so
+    the forward plan may compute it ahead of the trunk, on another stream."""
+    w_m = pack(tape, P[pre + ".mlp_mask.0.weight"])
+    actv = conv(tape, depth_map, w_m, P[pre + ".mlp_mask.0.bias"], act=ops.ACT_RELU)
+    w_gb = pack_pair(tape, P[pre + ".mlp_gamma_o.weight"], P[pre + ".mlp_beta_o.weight"])
+    b_gb = bias_pair(tape, P[pre + ".mlp_gamma_o.bias"], P[pre + ".mlp_beta_o.bias"])
+    return conv(tape, actv, w_gb, b_gb)
+
+
+def sean(tape, P, pre, t, depth_map, mask, st, residual, relu, consts, gb2=None):
     """SEAN.forward (normalization.py:52-92) + the caller's ReLU / residual."""
     B, H, W, C = t.data.shape
     assert st.data.shape[1] == mask.shape[1], "depth matrix regions != mask channels"   # normalization.py:54
@@ -277,12 +308,8 @@ def sean(tape, P, pre, t, depth_map, mask, st, residual, relu, consts):
         # the reference fails here inside nn.Conv2d (A_i_j expects depthRangeNum channels): same error class
         raise RuntimeError("SEAN.A_i_j expects %d depth regions, got %d mask channels"
                            % (P[pre + ".A_i_j.weight"].data.shape[0], st.data.shape[1]))
-    # gamma2 / beta2: a function of the depth map only
-    w_m = pack(tape, P[pre + ".mlp_mask.0.weight"])
-    actv = conv(tape, depth_map, w_m, P[pre + ".mlp_mask.0.bias"], act=ops.ACT_RELU)
-    w_gb = pack_pair(tape, P[pre + ".mlp_gamma_o.weight"], P[pre + ".mlp_beta_o.weight"])
-    b_gb = bias_pair(tape, P[pre + ".mlp_gamma_o.bias"], P[pre + ".mlp_beta_o.bias"])
-    gb2 = conv(tape, actv, w_gb, b_gb)
+    if gb2 is None:
+        gb2 = sean_depth_branch(tape, P, pre, depth_map)
     # gamma1 / beta1: per-sample dynamic kernels over the K-channel mask
     D = dynk(tape, st, P[pre + ".A_i_j.weight"], P[pre + ".A_i_j.bias"], P[pre + ".mlp_gamma_s.weight"],
              P[pre + ".mlp_beta_s.weight"])
@@ -292,17 +319,26 @@ def sean(tape, P, pre, t, depth_map, mask, st, residual, relu, consts):
                     residual, relu)
 
 
-def depth_block(tape, P, name, x, depth_map, mask, st, consts):
-    """Depth_Residual_Block_Mask.forward (sftmd_arch.py:826-834)."""
-    B, H, W, C = x.data.shape
-    if depth_map.data.shape[1:3] != (H, W):      # F.interpolate(..., mode='nearest'), normalization.py:58-59
+def block_depth_inputs(x_hw, depth_map, mask):
+    """Depth map / masks at the block's feature size: F.interpolate(..., mode='nearest'), normalization.py:58-59."""
+    B = depth_map.data.shape[0]
+    H, W = x_hw
+    if tuple(depth_map.data.shape[1:3]) != (H, W):
         d = ops.resize_nearest_nchw(depth_map.data.view(B, 1, *depth_map.data.shape[1:3]), H, W)
         depth_map = Var(d.view(B, H, W, 1))
         mask = MaskPack(ops.resize_nearest_nchw(mask.planes, H, W))
+    return depth_map, mask
+
+
+def depth_block(tape, P, name, x, depth_map, mask, st, consts, gb2_pair=None):
+    """Depth_Residual_Block_Mask.forward (sftmd_arch.py:826-834)."""
+    B, H, W, C = x.data.shape
+    depth_map, mask = block_depth_inputs((H, W), depth_map, mask)
+    g1, g2 = gb2_pair if gb2_pair is not None else (None, None)
     t1 = conv(tape, x, pack(tape, P[name + ".conv1.0.weight"]), P[name + ".conv1.0.bias"])
-    a = sean(tape, P, name + ".norm1", t1, depth_map, mask, st, None, True, consts)
+    a = sean(tape, P, name + ".norm1", t1, depth_map, mask, st, None, True, consts, g1)
     t2 = conv(tape, a, pack(tape, P[name + ".conv2.0.weight"]), P[name + ".conv2.0.bias"])
-    return sean(tape, P, name + ".norm2", t2, depth_map, mask, st, x, True, consts)
+    return sean(tape, P, name + ".norm2", t2, depth_map, mask, st, x, True, consts, g2)
 
 
 def classic_block(tape, P, name, x):
@@ -343,10 +379,40 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask):
     h1 = conv(tape, e1, _wn(tape, P, "head.0"), P["head.0.bias"], act=L)
     fea_bef = conv(tape, h1, _wn(tape, P, "head.2"), P["head.2.bias"], act=L)
 
+    # The depth-map branch of every SEAN (mlp_mask -> ReLU -> gamma_o|beta_o, 55 % of the forward FLOPs) depends on
+    # the depth map and parameters only: it is issued on a side HIP stream ahead of the trunk, and its backward runs
+    # there too, so its large convolutions fill the tails and small-kernel gaps of the trunk.
+    executed = list(range(nb - 3)) + [nb - 2, nb - 1]
+    branch = {}
+    side = _side_stream(inp.device) if (SIDE_STREAM and inp.is_cuda and mask_pack is not None) else None
+    if side is not None:
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        feat_hw = {}
+        hw = (x0.data.shape[1], x0.data.shape[2])
+        for i in executed:                 # feature size seen by block i (upscale1 before nb-2, upscale2 before nb-1)
+            if i == nb - 2 and scale == 8:
+                hw = (hw[0] * 2, hw[1] * 2)
+            if i == nb - 1 and scale >= 4:
+                hw = (hw[0] * 2, hw[1] * 2)
+            feat_hw[i] = hw
+        with tape.on_stream(side):
+            for i in executed:
+                name, kind, _ = plan[i]
+                if kind != "depth":
+                    continue
+                d_i, _m = block_depth_inputs(feat_hw[i], dm, mask_pack)
+                pair = []
+                for norm in (".norm1", ".norm2"):
+                    gb2 = sean_depth_branch(tape, P, name + norm, d_i)
+                    gb2.event = side.record_event()
+                    pair.append(gb2)
+                branch[i] = tuple(pair)
+
     def run_block(i, x):
         name, kind, _ = plan[i]
         if kind == "depth":
-            return depth_block(tape, P, name, x, dm, mask_pack, st, consts)
+            return depth_block(tape, P, name, x, dm, mask_pack, st, consts, branch.get(i))
         return classic_block(tape, P, name, x)
 
     fea = fea_bef

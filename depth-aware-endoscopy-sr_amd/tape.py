@@ -11,7 +11,8 @@ from . import ops
 
 class Var:
     """A device tensor plus its gradient slot."""
-    __slots__ = ("data", "grad", "requires_grad", "name", "uses", "epilogue", "grad_is_preact")
+    __slots__ = ("data", "grad", "requires_grad", "name", "uses", "epilogue", "grad_is_preact", "event",
+                 "grad_event")
 
     def __init__(self, data, requires_grad=False, name=None):
         self.data = data
@@ -21,6 +22,8 @@ class Var:
         self.uses = 0                # differentiable consumers recorded during the forward
         self.epilogue = None         # (act, ps_r) when produced by a conv with a fused activation / PixelShuffle
         self.grad_is_preact = False  # the consumer already applied the epilogue backward (dasr_conv2d_dgrad_act)
+        self.event = None            # HIP event after the producing kernel when it ran on another stream
+        self.grad_event = None       # HIP event after the kernel that produced .grad on another stream
 
     @property
     def shape(self):
@@ -28,17 +31,49 @@ class Var:
 
 
 class Tape:
+    """Backward closures in forward order.  A closure recorded inside ``on_stream(s)`` runs its backward on ``s``
+    too (the depth-map branch of every SEAN lives on a side stream, see graph.depthnet_forward)."""
+
     def __init__(self, enabled=True):
         self.enabled = enabled
         self.nodes = []
+        self._stream = None
+        self.side_streams = []
 
     def record(self, fn):
         if self.enabled:
-            self.nodes.append(fn)
+            self.nodes.append((fn, self._stream))
+
+    def on_stream(self, stream):
+        tape = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                import torch
+                self_inner.prev = tape._stream
+                tape._stream = stream
+                if stream not in tape.side_streams:
+                    tape.side_streams.append(stream)
+                self_inner.guard = torch.cuda.stream(stream)
+                self_inner.guard.__enter__()
+
+            def __exit__(self_inner, *exc):
+                self_inner.guard.__exit__(*exc)
+                tape._stream = self_inner.prev
+
+        return _Ctx()
 
     def backward(self):
+        import torch
         while self.nodes:
-            self.nodes.pop()()
+            fn, stream = self.nodes.pop()
+            if stream is None:
+                fn()
+            else:
+                with torch.cuda.stream(stream):
+                    fn()
+        for s in self.side_streams:          # parameter gradients produced on side streams are complete
+            torch.cuda.current_stream().wait_stream(s)
 
 
 def accum(var, g, owned=True):
