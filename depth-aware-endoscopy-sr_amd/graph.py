@@ -25,11 +25,14 @@ FUSE_DGRAD_ACT = False
 
 # Run the depth-map branch of the SEANs on a side HIP stream (forward and backward).
 SIDE_STREAM = True
+# Weight / bias gradients are off the critical path of the backward (nothing but the optimiser waits for them): they
+# run on a third stream and fill whatever the data-gradient chain leaves idle.
+WGRAD_STREAM = True
 _SIDE = {}
 
 
-def _side_stream(device):
-    key = str(device)
+def _side_stream(device, which="branch"):
+    key = (str(device), which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -46,6 +49,9 @@ def pack(tape, v, g=None, transposed=False):
     def bwd():
         if out.grad is None:
             return
+        if out.grad_event is not None:
+            torch.cuda.current_stream().wait_event(out.grad_event)
+            out.grad.record_stream(torch.cuda.current_stream())
         dv, dg = ops.weight_pack_bwd(out.grad, v.data, g.data if g is not None else None, inv, transposed)
         out.grad = None
         accum(v, dv)
@@ -68,6 +74,9 @@ def pack_pair(tape, va, vb):
     def bwd():
         if out.grad is None:
             return
+        if out.grad_event is not None:
+            torch.cuda.current_stream().wait_event(out.grad_event)
+            out.grad.record_stream(torch.cuda.current_stream())
         da, _ = ops.weight_pack_bwd(out.grad, va.data, None, None, False, o_off=0)
         db, _ = ops.weight_pack_bwd(out.grad, vb.data, None, None, False, o_off=Oa)
         out.grad = None
@@ -88,6 +97,9 @@ def bias_pair(tape, ba, bb):
     def bwd():
         if out.grad is None:
             return
+        if out.grad_event is not None:
+            torch.cuda.current_stream().wait_event(out.grad_event)
+            out.grad.record_stream(torch.cuda.current_stream())
         g = out.grad
         out.grad = None
         accum(ba, g[:na])
@@ -136,8 +148,23 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
         else:
             dconv = dy
         if w.requires_grad or (bias is not None and bias.requires_grad):
-            dw, db = ops.conv2d_wgrad(x.data, dconv, wshape, stride, pad, transposed,
-                                      want_bias=bias is not None)
+            ws = _side_stream(dconv.device, "wgrad") if (WGRAD_STREAM and dconv.is_cuda) else None
+            if ws is None:
+                dw, db = ops.conv2d_wgrad(x.data, dconv, wshape, stride, pad, transposed, want_bias=bias is not None)
+            else:
+                cur = torch.cuda.current_stream()
+                ready = cur.record_event()
+                if ws not in tape.side_streams:
+                    tape.side_streams.append(ws)
+                with torch.cuda.stream(ws):
+                    ws.wait_event(ready)
+                    dconv.record_stream(ws)
+                    dw, db = ops.conv2d_wgrad(x.data, dconv, wshape, stride, pad, transposed,
+                                              want_bias=bias is not None)
+                    done = ws.record_event()
+                w.grad_event = done
+                if bias is not None:
+                    bias.grad_event = done
             accum(w, dw)
             if bias is not None:
                 accum(bias, db)
