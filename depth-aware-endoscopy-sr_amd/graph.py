@@ -27,7 +27,7 @@ FUSE_DGRAD_ACT = False
 SIDE_STREAM = True
 # Weight / bias gradients are off the critical path of the backward (nothing but the optimiser waits for them): they
 # run on a third stream and fill whatever the data-gradient chain leaves idle.
-WGRAD_STREAM = True
+WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
 
 
