@@ -199,6 +199,20 @@ def main():
     elapsed = el.item()
     loss = float(trainer.log["l_all"])
 
+    # Roofline of the dynamic-conv forward kernel.  In the timed steps the kernel shares the GPU with the side
+    # stream's convolutions (graph.SIDE_STREAM), which stretches its duration and says nothing about the kernel, so
+    # ONE extra, untimed step is run with the side stream off and the same HIP-event timers: that is `achieved`;
+    # the duration seen inside the timed (overlapped) steps is reported next to it.
+    overlapped = timer.summary()
+    timer.pairs = []
+    from dasr_amd import graph as _graph
+    _side = _graph.SIDE_STREAM
+    _graph.SIDE_STREAM = False
+    timer.enabled = True
+    trainer.optimize_parameters(lq, gt, dm, mk)
+    torch.cuda.synchronize()
+    timer.enabled = False
+    _graph.SIDE_STREAM = _side
     roof = None
     s = timer.summary()
     if s is not None:
@@ -207,7 +221,13 @@ def main():
         roof = {"bound": "hbm", "kernel": "k_sean_fwd_onehot (dasr_sean_fwd: DGB dynamic conv + DFN modulation, forward)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches_timed": n,
-                "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes)}
+                "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
+                "measured": "HIP events on the launch stream, one extra un-overlapped step after the timed region"}
+        if overlapped is not None:
+            o_ms, o_bytes, o_n = overlapped
+            roof["in_timed_region"] = {"avg_launch_us": round(o_ms * 1e3, 2), "launches": o_n,
+                                       "achieved": round(o_bytes / (o_ms * 1e-3) / 1e9, 1),
+                                       "note": "co-running with the side-stream convolutions"}
         pmc = os.path.join(ROOT, "profiles", "sean_fwd_pmc.json")
         if os.path.exists(pmc):
             try:
