@@ -143,6 +143,14 @@ for case in DEPTHNET_CASES:
     (sr * wgt).sum().backward()
     lin = {"gl." + k: grad_digest(p.grad) for k, p in net.named_parameters() if p.grad is not None}
     net.zero_grad(set_to_none=True)
+    # (a64) the same functional with the reference run in float64 on the SAME fp32-valued parameters and inputs:
+    # the fp32 run above is itself ~1e-3 away from this on flip-prone cases, so the tight gate is against this one
+    net64 = ref_net(cfg).double()
+    sr64 = net64(lq.double(), dmap.double(), dmask.double())
+    (sr64 * wgt.double()).sum().backward()
+    lin.update({"gl64." + k: grad_digest(p.grad) for k, p in net64.named_parameters() if p.grad is not None})
+    lin["sr64"] = sr64.detach().numpy()
+    del net64, sr64
     # (b) the training loss of the reference harness
     sr = net(lq, dmap, dmask)
     dyn = mask_loss.dynamic_weight_mask_loss(opt_dyn, num_trainable_para=cfg["depthRangeNum"])
