@@ -177,6 +177,26 @@ def test_depthnet_matches_reference(case, golden_dir):
         assert ok, (k, err, scale)
 
 
+@pytest.mark.parametrize("case", DEPTHNET_CASES, ids=[c["name"] for c in DEPTHNET_CASES])
+def test_depthnet_fp64_matches_reference_fp64(case, golden_dir):
+    """The oracle run in float64 against the reference run in float64 on the same fp32-valued parameters:
+    algorithmic identity to 1e-9, with no fp32 rounding (or ReLU flips) in the way."""
+    g = _load(golden_dir, "depthnet_" + case["name"])
+    cfg = make_case_cfg(case)
+    sd = {k: v.detach().double().requires_grad_(True) for k, v in _sd(O.param_shapes(cfg), requires_grad=False).items()}
+    lq, gt, dmap, dmask = synth.closed_form_batch(0, case["B"], case["H"], case["W"], cfg["scale"])
+    sr = O.depthnet_forward(sd, cfg, lq.double(), dmap.double(), dmask.double())
+    assert np.abs(sr.detach().numpy() - g["sr64"]).max() <= 1e-11
+    wgt = torch.cos(torch.arange(sr.numel(), dtype=torch.float32) * 0.013).reshape(sr.shape).double()
+    (sr * wgt).sum().backward()
+    nograd = set(g["nograd"].tolist())
+    for k, v in sd.items():
+        if k in nograd:
+            continue
+        ok, err, scale = digest_close(v.grad, g["gl64." + k], rtol=1e-9, atol=1e-12)
+        assert ok, (k, err, scale)
+
+
 def test_state_dict_keys_match_reference(golden_dir):
     keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
     for scale, which, L in ((8, list(range(14)), 256), (4, list(range(14)), 256), (2, list(range(16)), 32)):
