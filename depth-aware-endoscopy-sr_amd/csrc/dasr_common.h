@@ -12,12 +12,17 @@
     hipemu::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
 #define DASR_DYN_SMEM(name) char* name = hipemu::dyn_smem
 #define DASR_DEVICE_BUILD 0
+#define DASR_UNIFORM(x) (x)
+#define DASR_SCHED_BARRIER() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define DASR_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (hipStream_t)(stream), __VA_ARGS__)
 #define DASR_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define DASR_DEVICE_BUILD 1
+// a value the program knows to be the same in every lane of the wave: move it to an SGPR
+#define DASR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#define DASR_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif

@@ -324,23 +324,41 @@ extern "C" int dasr_mask_compress(const float* mask, unsigned char* region, int*
     DASR_RETURN_LAUNCH_STATUS();
 }
 
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ float4 ld_nt4(const float* p) {
     f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
     return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st_nt4(float* p, float4 v) {
+#if DASR_DEVICE_BUILD
+    f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (f32x4*)p);
+#else
+    *(float4*)p = v;
+#endif
 }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // Stage D[b] (channel slice c0..c0+63) as [18][K+1][64] with a zero row K ("no region": outside the image
 // or a pixel no mask claims); float4 copies, 16 threads per 64-channel row.
-__device__ __forceinline__ void sean_stage_D(const SeanGeom& g, const float* __restrict__ D, float* sD, int b, int c0) {
+// With bias_g / bias_b given, the conv biases are folded into the tap-0 rows (bias + row, the first addition of the
+// gather's fixed summation order, so the result is bit-identical to adding the bias first).
+__device__ __forceinline__ void sean_stage_D(const SeanGeom& g, const float* __restrict__ D, float* sD, int b, int c0,
+                                             const float* __restrict__ bias_g = nullptr,
+                                             const float* __restrict__ bias_b = nullptr) {
     const int K1 = g.K + 1;
     const int q = threadIdx.x & 15;
+    const bool inC = c0 + 4 * q + 3 < g.C;
     for (int r = threadIdx.x >> 4; r < 18 * K1; r += blockDim.x >> 4) {
         const int st = r / K1, k = r - st * K1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < g.K) {
             const float* src = D + (((size_t)b * 18 + st) * g.K + k) * g.C + c0 + 4 * q;
-            if (c0 + 4 * q + 3 < g.C) v = *(const float4*)src;
+            if (inC) v = *(const float4*)src;
+        }
+        if (bias_g && inC && (st == 0 || st == 9)) {
+            const float4 bv = *(const float4*)((st == 0 ? bias_g : bias_b) + c0 + 4 * q);
+            v = make_float4(bv.x + v.x, bv.y + v.y, bv.z + v.z, bv.w + v.w);
         }
         *(float4*)(sD + r * 64 + 4 * q) = v;
     }
@@ -355,65 +373,118 @@ __device__ __forceinline__ void sean_stage_R(const SeanGeom& g, const unsigned c
         sR[i] = v;
     }
 }
-// gamma1 / beta1 of tile-local pixel (ly, lx): 9 row gathers from sD
+// gamma1 / beta1 of tile-local pixel (ly, lx): 9 row gathers from sD each (same summation order as the general
+// kernel: bias, then taps 0..8).  The scheduling barrier keeps the 9 gamma rows and the 9 beta rows from being
+// in registers at the same time (the fwd kernel must stay within 168 VGPRs for 3 waves per SIMD).
 __device__ __forceinline__ void sean_gather(const float* sD, const unsigned char* sR, int K1, int ly, int lx, int cq,
                                             float4 bg, float4 bb, float4& g1, float4& b1) {
+    int k[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) k[tap] = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
     g1 = bg;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k[tap]) * 64 + 4 * cq));
+    DASR_SCHED_BARRIER();
     b1 = bb;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int k = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
-        g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k) * 64 + 4 * cq));
-        b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k) * 64 + 4 * cq));
-    }
+    for (int tap = 0; tap < 9; ++tap) b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k[tap]) * 64 + 4 * cq));
+}
+// the same with the biases already folded into the tap-0 rows (sean_stage_D with bias pointers)
+__device__ __forceinline__ void sean_gather_folded(const float* sD, const unsigned char* sR, int K1, int ly, int lx,
+                                                   int cq, float4& g1, float4& b1) {
+    int k[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) k[tap] = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
+    g1 = *(const float4*)(sD + ((0 * 9 + 0) * K1 + k[0]) * 64 + 4 * cq);
+#pragma unroll
+    for (int tap = 1; tap < 9; ++tap) g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k[tap]) * 64 + 4 * cq));
+    DASR_SCHED_BARRIER();
+    b1 = *(const float4*)(sD + ((1 * 9 + 0) * K1 + k[0]) * 64 + 4 * cq);
+#pragma unroll
+    for (int tap = 1; tap < 9; ++tap) b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k[tap]) * 64 + 4 * cq));
+    DASR_SCHED_BARRIER();
 }
 
-// Forward.  Workgroup = 256 threads, tile = 8 rows x 32 columns; wave w owns rows w and w+4.  Per row the wave
-// issues the global loads of four 4-pixel steps (16 pixels) before it consumes any, so ~16 KiB per wave are in
-// flight; a lane holds 4 channels of one pixel (float4), a wave-instruction moves 4 x 256 B contiguous.
-__global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float* __restrict__ t,
-                                                         const float* __restrict__ mean, const float* __restrict__ var,
-                                                         const float* __restrict__ gb2,
-                                                         const unsigned char* __restrict__ region,
-                                                         const int* __restrict__ flag, const float* __restrict__ D,
-                                                         const float* __restrict__ bias_g,
-                                                         const float* __restrict__ bias_b,
-                                                         const float* __restrict__ alpha_g,
-                                                         const float* __restrict__ alpha_b,
-                                                         const float* __restrict__ residual, float* __restrict__ out,
-                                                         int relu, float eps, int tiles_per_wg) {
-    if (flag && *flag != 0) return;   // masks are not one-hot: the general kernel does the work
+// Forward.  Workgroup = 256 threads, tile = SF_TH rows x 32 columns; wave w owns rows w, w+4, ...  A lane holds 4
+// channels of one pixel (float4), a wave-instruction moves 4 x 256 B contiguous.
+//
+// The streaming loop is written so that the compiler can keep TWO groups of loads in flight per wave: loads are
+// unconditional (coordinates clamped into the image, only the store is predicated), RELU / HAS_RES are template
+// parameters, and every load is "scalar row pointer + 32-bit per-lane byte offset" (SGPR-base form, no 64-bit
+// address registers; a row is W*2C*4 bytes, far below 4 GiB).  With predicated loads the join of the
+// skipped-consume path forced `s_waitcnt vmcnt(0)` at the loop head (a pending load into a register about to be
+// overwritten), which serialised the two buffers.  The first group of a tile is requested before the tile's D /
+// region staging (and, for the first tile, before the one-hot flag is even known), so the staging latency and the
+// two barriers are covered by loads in flight.
+struct SeanTile { int b, y0, x0; };
+
+template <bool RELU, bool HAS_RES>
+__global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const float* __restrict__ t,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ var,
+                                                            const float* __restrict__ gb2,
+                                                            const unsigned char* __restrict__ region,
+                                                            const int* __restrict__ flag, const float* __restrict__ D,
+                                                            const float* __restrict__ bias_g,
+                                                            const float* __restrict__ bias_b,
+                                                            const float* __restrict__ alpha_g,
+                                                            const float* __restrict__ alpha_b,
+                                                            const float* __restrict__ residual,
+                                                            float* __restrict__ out, float eps, int tiles_per_wg) {
     DASR_DYN_SMEM(smem);
+    constexpr int TH = SF_TH, NG = TH;                         // NG groups of 8 pixels per wave and tile (TH/4 rows x 4)
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                                  // [18][K+1][64]
     unsigned char* sR = (unsigned char*)(sD + 18 * K1 * 64);   // [(TH+2)*(TW+2)]
-    const int tiles_x = (g.W + SF_TW - 1) / SF_TW, tiles_y = (g.H + SF_TH - 1) / SF_TH;
+    const int tiles_x = (g.W + SF_TW - 1) / SF_TW, tiles_y = (g.H + TH - 1) / TH;
     const int tiles_per_sample = tiles_x * tiles_y;
     const int c0 = blockIdx.y * 64;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = DASR_UNIFORM((int)(threadIdx.x >> 6));
     const int cq = lane & 15, ps = lane >> 4;
-    const int c = c0 + 4 * cq;
-    const bool live = c < g.C;
-    const float a_g = alpha_g[0], a_b = alpha_b[0];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 bg = zero4, bb = zero4;
-    if (live) {
-        bg = *(const float4*)(bias_g + c);
-        bb = *(const float4*)(bias_b + c);
-    }
+    const bool live = c0 + 4 * cq < g.C;
+    const int c = live ? c0 + 4 * cq : 0;                      // dead lanes (C % 64 != 0) shadow channel 0, never store
     // Persistent workgroup: a contiguous chunk of (sample, tile) pairs; D[b] is restaged only when the sample
-    // changes, so its 50 KB L2->LDS copy is paid about once per workgroup instead of once per 256-pixel tile.
+    // changes, so its 50 KB L2->LDS copy is paid about once per workgroup instead of once per tile.
     const int first = blockIdx.x * tiles_per_wg;
     int last = first + tiles_per_wg;
     if (last > g.B * tiles_per_sample) last = g.B * tiles_per_sample;
+    if (first >= last) return;
+    auto tile_of = [&](int tt) {
+        const int tile = tt % tiles_per_sample;
+        return SeanTile{tt / tiles_per_sample, (tile / tiles_x) * TH, (tile % tiles_x) * SF_TW};
+    };
+    struct Buf { float4 tv[2], g2[2], b2[2], rv[2]; };
+    auto issue = [&](const SeanTile& T, int grp, Buf& f) {
+        const int y = imin(T.y0 + wv + 4 * (grp >> 2), g.H - 1);                // wave-uniform
+        const size_t row = ((size_t)T.b * g.H + y) * g.W;                       // scalar
+        const char* trow = (const char*)(t + row * g.C);
+        const char* grow = (const char*)(gb2 + row * 2 * g.C);
+        const char* brow = grow + (size_t)g.C * 4;                              // beta half of the (gamma2 | beta2) pair
+        const char* rrow = HAS_RES ? (const char*)(residual + row * g.C) : nullptr;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned x = (unsigned)imin(T.x0 + 8 * (grp & 3) + 4 * u + ps, g.W - 1);
+            const unsigned ot = (x * (unsigned)g.C + (unsigned)c) * 4u;
+            const unsigned og = (x * 2u * (unsigned)g.C + (unsigned)c) * 4u;
+            f.tv[u] = ld_nt4((const float*)(trow + ot));                        // streamed once: keep D / halos cached
+            f.g2[u] = ld_nt4((const float*)(grow + og));
+            f.b2[u] = ld_nt4((const float*)(brow + og));
+            if (HAS_RES) f.rv[u] = *(const float4*)(rrow + ot);
+        }
+    };
+    Buf fa, fb;
+    SeanTile T = tile_of(first);
+    issue(T, 0, fa);
+    if (flag && *flag != 0) return;   // masks are not one-hot: the general kernel does the work
+    const float a_g = alpha_g[0], a_b = alpha_b[0];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int cur_b = -1;
     float4 mu = zero4, sc = zero4;
     for (int tt = first; tt < last; ++tt) {
-        const int b = tt / tiles_per_sample, tile = tt % tiles_per_sample;
-        const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SF_TH;
+        const int b = T.b, y0 = T.y0, x0 = T.x0;
         __syncthreads();                                   // previous tile is done with sR (and sD)
         if (b != cur_b) {
-            sean_stage_D(g, D, sD, b, c0);
+            sean_stage_D(g, D, sD, b, c0, bias_g, bias_b);
             cur_b = b;
             if (live) {
                 mu = *(const float4*)(mean + (size_t)b * g.C + c);
@@ -422,59 +493,49 @@ __global__ void __launch_bounds__(256) k_sean_fwd_onehot(SeanGeom g, const float
                                  dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
             }
         }
-        sean_stage_R(g, region, sR, b, y0, x0, SF_TH);
+        sean_stage_R(g, region, sR, b, y0, x0, TH);
         __syncthreads();
-        if (!live) continue;
-        // This wave's pixels of the tile: rows wv and wv+4, 8 groups of 8 pixels (two 4-pixel steps).  The loads
-        // of group n+1 are issued before group n is consumed (two register buffers, statically named), so every
-        // wave keeps 6-8 KiB of HBM reads in flight while it gathers and modulates.
-        struct Buf { float4 tv[2], g2[2], b2[2], rv[2]; };
-        auto issue = [&](int grp, Buf& f) {
-            const int ly = wv + 4 * (grp >> 2), y = y0 + ly;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int x = x0 + 8 * (grp & 3) + 4 * u + ps;
-                f.tv[u] = zero4; f.g2[u] = zero4; f.b2[u] = zero4; f.rv[u] = zero4;
-                if (y < g.H && x < g.W) {
-                    const size_t p = ((size_t)b * g.H + y) * g.W + x;
-                    f.tv[u] = ld_nt4(t + p * g.C + c);      // streamed once: keep it out of the way of D / halos
-                    f.g2[u] = ld_nt4(gb2 + p * 2 * g.C + c);
-                    f.b2[u] = ld_nt4(gb2 + p * 2 * g.C + g.C + c);
-                    if (residual) f.rv[u] = *(const float4*)(residual + p * g.C + c);
-                }
-            }
-        };
         auto consume = [&](int grp, const Buf& f) {
             const int ly = wv + 4 * (grp >> 2), y = y0 + ly;
-            if (y >= g.H) return;
+            const size_t row = ((size_t)b * g.H + imin(y, g.H - 1)) * g.W;
+            char* orow = (char*)(out + row * g.C);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int lx = 8 * (grp & 3) + 4 * u + ps, x = x0 + lx;
-                if (x >= g.W) continue;
-                const size_t p = ((size_t)b * g.H + y) * g.W + x;
                 float4 g1, b1;
-                sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
+                sean_gather_folded(sD, sR, K1, ly, lx, cq, g1, b1);
                 float4 o;
-                o.x = (f.tv[u].x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * f.g2[u].x) + a_b * b1.x + (1.f - a_b) * f.b2[u].x + f.rv[u].x;
-                o.y = (f.tv[u].y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * f.g2[u].y) + a_b * b1.y + (1.f - a_b) * f.b2[u].y + f.rv[u].y;
-                o.z = (f.tv[u].z - mu.z) * sc.z * (1.f + a_g * g1.z + (1.f - a_g) * f.g2[u].z) + a_b * b1.z + (1.f - a_b) * f.b2[u].z + f.rv[u].z;
-                o.w = (f.tv[u].w - mu.w) * sc.w * (1.f + a_g * g1.w + (1.f - a_g) * f.g2[u].w) + a_b * b1.w + (1.f - a_b) * f.b2[u].w + f.rv[u].w;
-                if (relu) {
+                o.x = (f.tv[u].x - mu.x) * sc.x * (1.f + a_g * g1.x + (1.f - a_g) * f.g2[u].x) + a_b * b1.x + (1.f - a_b) * f.b2[u].x;
+                o.y = (f.tv[u].y - mu.y) * sc.y * (1.f + a_g * g1.y + (1.f - a_g) * f.g2[u].y) + a_b * b1.y + (1.f - a_b) * f.b2[u].y;
+                o.z = (f.tv[u].z - mu.z) * sc.z * (1.f + a_g * g1.z + (1.f - a_g) * f.g2[u].z) + a_b * b1.z + (1.f - a_b) * f.b2[u].z;
+                o.w = (f.tv[u].w - mu.w) * sc.w * (1.f + a_g * g1.w + (1.f - a_g) * f.g2[u].w) + a_b * b1.w + (1.f - a_b) * f.b2[u].w;
+                if (HAS_RES) { o.x += f.rv[u].x; o.y += f.rv[u].y; o.z += f.rv[u].z; o.w += f.rv[u].w; }
+                if (RELU) {
                     o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
                     o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
                 }
-                *(float4*)(out + p * g.C + c) = o;
+                if (live && y < g.H && x < g.W) {
+                    float* dst = (float*)(orow + ((unsigned)x * (unsigned)g.C + (unsigned)c) * 4u);
+                    st_nt4(dst, o);       // written once, read by the next kernel from HBM: do not displace the inputs
+                }
             }
         };
-        Buf fa, fb;
-        issue(0, fa);
+        // Two statically named register buffers: group n+1 is requested before group n is consumed, so a wave keeps
+        // 6-16 KiB of HBM reads in flight while it gathers and modulates.  fa already holds group 0 of this tile.
 #pragma unroll 1
-        for (int grp = 0; grp < 8; grp += 2) {
-            issue(grp + 1, fb);
+        for (int grp = 0; grp < NG - 2; grp += 2) {
+            issue(T, grp + 1, fb);
             consume(grp, fa);
-            if (grp + 2 < 8) issue(grp + 2, fa);
+            issue(T, grp + 2, fa);
             consume(grp + 1, fb);
         }
+        issue(T, NG - 1, fb);
+        consume(NG - 2, fa);
+        if (tt + 1 < last) {
+            T = tile_of(tt + 1);
+            issue(T, 0, fa);
+        }
+        consume(NG - 1, fb);
     }
 }
 
@@ -707,8 +768,12 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
         int per = (tiles * slices + 767) / 768;            // 256 CUs x 3 resident workgroups (51 KB of LDS each)
         if (per < 1) per = 1;
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
-        DASR_LAUNCH(k_sean_fwd_onehot, dim3((tiles + per - 1) / per, slices), dim3(256), lds, stream, g, t, mean, var,
-                    gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps, per);
+#define SEAN_FWD_GO(RELU, RES)                                                                                     \
+    DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES>), dim3((tiles + per - 1) / per, slices), dim3(256), lds, stream, g, t,  \
+                mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, eps, per)
+        if (relu) { if (residual) SEAN_FWD_GO(true, true); else SEAN_FWD_GO(true, false); }
+        else      { if (residual) SEAN_FWD_GO(false, true); else SEAN_FWD_GO(false, false); }
+#undef SEAN_FWD_GO
     }
     if (!fast_only) {
         int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
