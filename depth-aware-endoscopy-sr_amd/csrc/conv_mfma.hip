@@ -25,6 +25,27 @@
 #define CM_CKP 20
 #define CM_HALO_W (CM_TW + 2)
 
+// Phase timing of the forward kernel (tools/conv_phase_timing.py builds a private copy with -DDASR_CONV_TIMING;
+// never defined in the shipped library).
+#ifdef DASR_CONV_TIMING
+__device__ unsigned long long g_cm_phase[8];
+#define CM_T_DECL unsigned long long cm_tprev = __builtin_readcyclecounter(), cm_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CM_T_MARK(i) do { unsigned long long cm_now = __builtin_readcyclecounter(); cm_tacc[i] += cm_now - cm_tprev; cm_tprev = cm_now; } while (0)
+#define CM_T_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int cm_i = 0; cm_i < 8; ++cm_i) atomicAdd(&g_cm_phase[cm_i], cm_tacc[cm_i]); } while (0)
+extern "C" int dasr_debug_conv_phase_read(unsigned long long* host8, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_cm_phase), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_cm_phase), z, sizeof(z));
+    }
+    return (int)e;
+}
+#else
+#define CM_T_DECL
+#define CM_T_MARK(i)
+#define CM_T_FLUSH()
+#endif
+
 struct ConvMfmaArgs {
     const float* x;         // [B,H,W,Cin]
     const float* w;         // packed kernel of the FORWARD conv: HWIO then per-tap transpose (dasr_weight_pack_fwd)
@@ -115,12 +136,18 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
             }
         }
     };
+    CM_T_DECL;
     prefetch(0);
+    CM_T_MARK(0);
     for (int c0 = 0; c0 < a.Cin; c0 += CM_CK) {
         __syncthreads();                       // every wave is done reading the previous chunk
+        CM_T_MARK(1);
         commit();
+        CM_T_MARK(2);
         __syncthreads();
+        CM_T_MARK(3);
         if (c0 + CM_CK < a.Cin) prefetch(c0 + CM_CK);
+        CM_T_MARK(4);
         // ---- 9 taps x 16 channels = 18 fragment steps of 4 K=2 MFMAs per accumulator.  The LDS reads of step j+1
         // are issued before the MFMAs of step j (two statically named fragment sets), so the matrix pipe never
         // waits for a ds_read at the start of a step.
@@ -154,9 +181,69 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
             if (j + 2 < 18) ldfrag(j + 2, A0, B0);
             mma(A1, B1);
         }
+        CM_T_MARK(5);
     }
     // ---- epilogue
     const int rr = a.ps_r * a.ps_r;
+    // Fast path (full-width tiles, the usual case): every address is "scalar row base + scalar pixel offset + one
+    // per-lane 32-bit byte offset", the optional residual / accumulate operands are fetched for all 16 pixels of a
+    // fragment before the first store, and the activation is branch-free.  The generic path below spends ~40 VALU
+    // instructions and several scalar branches per ELEMENT on 64-bit index arithmetic (measured: 15 % of the
+    // 128->128 kernel, 32 % of the 64->64 one).
+    if (!UNMASK && x0 + CM_TW <= a.W && !(a.ps_r > 1 && a.residual != nullptr)) {
+        const int wvu = DASR_UNIFORM(wv);
+        const int ps = a.ps_r, Cq = a.Cout / rr;
+        const unsigned pstride = (unsigned)(ps > 1 ? ps * Cq : a.Cout) * 4u;      // bytes between x and x+1 for one lane
+        const bool is_relu = a.act == DASR_ACT_RELU;
+        const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int gy = y0 + 2 * wvu + m;
+            if (gy >= a.H) continue;
+            // scalar element index of (b, gy, x0) in the output (through the PixelShuffle map when ps > 1)
+            const size_t obase = ps > 1 ? (((size_t)b * a.H * ps + (size_t)gy * ps) * ((size_t)a.W * ps) + (size_t)x0 * ps) * Cq
+                                        : (((size_t)b * a.H + gy) * a.W + x0) * a.Cout;
+            char* yrow = (char*)(a.y + obase);
+            const char* rrow = a.residual ? (const char*)(a.residual + obase) : nullptr;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = n0 + 32 * n + li;
+                const float bv = a.bias ? a.bias[co] : 0.f;
+                unsigned loff;                                                    // this lane's byte offset in the row
+                if (ps > 1) {
+                    const int c = co / rr, i = (co / ps) % ps, j = co % ps;
+                    loff = ((unsigned)(i * a.W * ps + j) * (unsigned)Cq + (unsigned)c) * 4u + 4u * lh * pstride;
+                } else {
+                    loff = (unsigned)co * 4u + 4u * lh * pstride;
+                }
+                float rv[16], av[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = av[r] = 0.f;
+                if (rrow) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rv[r] = *(const float*)((rrow + (size_t)(((r & 3) + 8 * (r >> 2)) * pstride)) + loff);
+                }
+                if (a.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        av[r] = *(const float*)((yrow + (size_t)(((r & 3) + 8 * (r >> 2)) * pstride)) + loff);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[m][n][r] + bv;
+                    if (rrow) v += rv[r];
+                    const float neg = is_relu ? 0.f : v * slope;
+                    v = v > 0.f ? v : neg;
+                    if (a.accumulate) v += av[r];
+                    *(float*)((yrow + (size_t)(((r & 3) + 8 * (r >> 2)) * pstride)) + loff) = v;
+                }
+            }
+        }
+        CM_T_MARK(6);
+        CM_T_FLUSH();
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int gy = y0 + 2 * wv + m;
@@ -192,6 +279,8 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
             }
         }
     }
+    CM_T_MARK(6);
+    CM_T_FLUSH();
 }
 
 static size_t conv_mfma_lds(int NT, int TH) {
