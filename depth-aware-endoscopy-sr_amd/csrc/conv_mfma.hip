@@ -74,9 +74,17 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
     constexpr int NTILE = 32 * NT;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int tiles_x = (a.W + CM_TW - 1) / CM_TW;
-    const int x0 = (blockIdx.x % tiles_x) * CM_TW, y0 = (blockIdx.x / tiles_x) * CM_TH;
-    const int b = blockIdx.y, n0 = blockIdx.z * NTILE;
+    // XCD-aware block order (1-D grid): consecutive workgroup ids are dealt round-robin to the 8 XCDs, so the
+    // N-slices of one pixel tile get ids 8 apart - same XCD, back to back - and the second one finds the input
+    // tile in that XCD's L2 instead of fetching it from HBM again.
+    const int tiles_x = (a.W + CM_TW - 1) / CM_TW, tiles_y = (a.H + CM_TH - 1) / CM_TH;
+    const int nsl = a.Cout / NTILE, G = tiles_x * tiles_y * a.B;
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int gt = (kq / nsl) * 8 + xcd;
+    if (gt >= G) return;
+    const int tile = gt % (tiles_x * tiles_y);
+    const int x0 = (tile % tiles_x) * CM_TW, y0 = (tile / tiles_x) * CM_TH;
+    const int b = gt / (tiles_x * tiles_y), n0 = (kq % nsl) * NTILE;
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -294,10 +302,16 @@ bool conv_mfma_supported(const ConvGeom& g) {
 
 template <int WMODE>
 static int launch_conv_mfma(ConvMfmaArgs& a, void* stream) {
-    const int TH = (a.H % 16) == 0 ? 16 : 8;
-    int tiles = ((a.W + CM_TW - 1) / CM_TW) * ((a.H + TH - 1) / TH);
+    // 16-row tiles (one 512-thread workgroup per CU) stage every weight slice once for twice the pixels; 8-row
+    // tiles (two 256-thread workgroups per CU) overlap one workgroup's barriers / prologue / epilogue with the
+    // other's matrix work and halve the tail.  Measured (B=16): 16 rows win when the 16-row grid fills whole rounds
+    // of the 256 CUs or is many rounds long, 8 rows win otherwise (64->64 at 128x160: 264 -> 238 us).
     const bool nt2 = (a.Cout % 64) == 0;
-    const dim3 grid(tiles, a.B, a.Cout / (nt2 ? 64 : 32));
+    const long wg16 = (long)((a.W + CM_TW - 1) / CM_TW) * ((a.H + 15) / 16) * a.B * (a.Cout / (nt2 ? 64 : 32));
+    const int TH = ((a.H % 16) == 0 && (wg16 % 256 == 0 || wg16 >= 2048)) ? 16 : 8;
+    int tiles = ((a.W + CM_TW - 1) / CM_TW) * ((a.H + TH - 1) / TH);
+    const int G8 = (tiles * a.B + 7) / 8 * 8;                 // pixel tiles, padded to whole rounds over the 8 XCDs
+    const dim3 grid(G8 * (a.Cout / (nt2 ? 64 : 32)));
     const dim3 block(32 * TH);
     const size_t lds = conv_mfma_lds(nt2 ? 2 : 1, TH);
     const bool um = a.mask_src != nullptr;
