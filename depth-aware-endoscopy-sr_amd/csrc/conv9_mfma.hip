@@ -50,23 +50,40 @@ __global__ void __launch_bounds__(256) k_conv9x9_fwd_mfma(Conv9Args a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     for (int c0 = 0; c0 < a.Cin; c0 += C9_CK) {
-        __syncthreads();
-        for (int idx = tid; idx < (C9_TH + 8) * C9_TQ * (C9_CK / 4); idx += 256) {
-            int q4 = idx % (C9_CK / 4), pix = idx / (C9_CK / 4);
-            int gy = y0 - 4 + pix / C9_TQ, gx = x0 - 4 + pix % C9_TQ;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        // all global loads of the chunk are issued before the barrier and the first LDS write ("load; wait; write"
+        // loops are chains of dependent round trips: 17 per chunk here)
+        constexpr int NIN9 = (C9_TH + 8) * C9_TQ * (C9_CK / 4) / 256, NW9 = 9 * 32 * C9_CK / 256;
+        float4 vin[NIN9];
+        float vw[NW9];
+#pragma unroll
+        for (int u = 0; u < NIN9; ++u) {
+            const int idx = tid + 256 * u;
+            const int q4 = idx % (C9_CK / 4), pix = idx / (C9_CK / 4);
+            const int gy = y0 - 4 + pix / C9_TQ, gx = x0 - 4 + pix % C9_TQ;
+            vin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
-            *(float4*)(sIn + pix * C9_CKP + 4 * q4) = v;
+                vin[u] = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
         }
-        for (int idx = tid; idx < 9 * 32 * C9_CK; idx += 256) {
-            int k = idx % C9_CK, n = (idx / C9_CK) % 32, kh = idx / (C9_CK * 32);
-            float v = 0.f;
+#pragma unroll
+        for (int u = 0; u < NW9; ++u) {
+            const int idx = tid + 256 * u;
+            const int k = idx % C9_CK, n = (idx / C9_CK) % 32, kh = idx / (C9_CK * 32);
+            vw[u] = 0.f;
             if (n < NN) {
-                int kw = n / a.Cout, co = n % a.Cout;
-                v = a.w[(((size_t)kh * 9 + kw) * a.Cin + c0 + k) * a.Cout + co];
+                const int kw = n / a.Cout, co = n % a.Cout;
+                vw[u] = a.w[(((size_t)kh * 9 + kw) * a.Cin + c0 + k) * a.Cout + co];
             }
-            sW[(kh * 32 + n) * C9_CKP + k] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NIN9; ++u) {
+            const int idx = tid + 256 * u;
+            *(float4*)(sIn + (idx / (C9_CK / 4)) * C9_CKP + 4 * (idx % (C9_CK / 4))) = vin[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NW9; ++u) {
+            const int idx = tid + 256 * u;
+            sW[((idx / (C9_CK * 32)) * 32 + (idx / C9_CK) % 32) * C9_CKP + idx % C9_CK] = vw[u];
         }
         __syncthreads();
 #pragma unroll 3
@@ -114,18 +131,27 @@ __global__ void __launch_bounds__(256) k_conv9x9_fwd_mfma(Conv9Args a) {
 
 // ------------------------------------------------------------------------------------------ dgrad
 // tile: 8 rows x 64 columns of dx pixels x 32 input channels (blockIdx.z selects the 32-channel slice)
-__device__ __forceinline__ void c9_stage_dy(const Conv9Args& a, float* sDy, int b, int y0, int x0, int tid) {
+#define C9_NDY (((C9_TH + 8) * C9_DYW + 255) / 256)
+__device__ __forceinline__ void c9_load_dy(const Conv9Args& a, float (&v)[C9_NDY], int b, int y0, int x0, int tid) {
     // rows y0-4 .. y0+11, columns x0-4 .. x0+67, Cout channels interleaved; zero outside the image
     const int rowf = (C9_TQ + 8) * a.Cout;
-    for (int idx = tid; idx < (C9_TH + 8) * C9_DYW; idx += 256) {
-        int f = idx % C9_DYW, ry = idx / C9_DYW;
-        float v = 0.f;
-        if (f < rowf) {
-            int gy = y0 - 4 + ry, gx = x0 - 4 + f / a.Cout, co = f % a.Cout;
+#pragma unroll
+    for (int u = 0; u < C9_NDY; ++u) {
+        const int idx = tid + 256 * u;
+        const int f = idx % C9_DYW, ry = idx / C9_DYW;
+        v[u] = 0.f;
+        if (idx < (C9_TH + 8) * C9_DYW && f < rowf) {
+            const int gy = y0 - 4 + ry, gx = x0 - 4 + f / a.Cout, co = f % a.Cout;
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = a.dy[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co];
+                v[u] = a.dy[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co];
         }
-        sDy[idx] = v;
+    }
+}
+__device__ __forceinline__ void c9_store_dy(float* sDy, const float (&v)[C9_NDY], int tid) {
+#pragma unroll
+    for (int u = 0; u < C9_NDY; ++u) {
+        const int idx = tid + 256 * u;
+        if (idx < (C9_TH + 8) * C9_DYW) sDy[idx] = v[u];
     }
 }
 
@@ -139,15 +165,27 @@ __global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
     const int x0 = (blockIdx.x % tiles_x) * C9_TQ, y0 = (blockIdx.x / tiles_x) * C9_TH, b = blockIdx.y;
     const int n0 = blockIdx.z * 32;
     const int KK = 9 * a.Cout;   // 27 live k' per kh
-    c9_stage_dy(a, sDy, b, y0, x0, tid);
-    for (int idx = tid; idx < 9 * 28 * 32; idx += 256) {
-        int ci = idx & 31, kp = (idx >> 5) % 28, kh = idx / (28 * 32);
-        float v = 0.f;
-        if (kp < KK) {
-            int kw = 8 - kp / a.Cout, co = kp % a.Cout;
-            v = a.w[(((size_t)kh * 9 + kw) * a.Cin + n0 + ci) * a.Cout + co];
+    {
+        float vdy[C9_NDY];
+        c9_load_dy(a, vdy, b, y0, x0, tid);
+        constexpr int NWD = (9 * 28 * 32 + 255) / 256;       // 32 (the last one half used)
+        float vw[NWD];
+#pragma unroll
+        for (int u = 0; u < NWD; ++u) {
+            const int idx = tid + 256 * u;
+            const int ci = idx & 31, kp = (idx >> 5) % 28, kh = idx / (28 * 32);
+            vw[u] = 0.f;
+            if (idx < 9 * 28 * 32 && kp < KK) {
+                const int kw = 8 - kp / a.Cout, co = kp % a.Cout;
+                vw[u] = a.w[(((size_t)kh * 9 + kw) * a.Cin + n0 + ci) * a.Cout + co];
+            }
         }
-        sW[idx] = v;
+        c9_store_dy(sDy, vdy, tid);
+#pragma unroll
+        for (int u = 0; u < NWD; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < 9 * 28 * 32) sW[idx] = vw[u];
+        }
     }
     __syncthreads();
     f32x16 acc[4];
@@ -196,7 +234,7 @@ __global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
 // Workgroup walks a strip of 8 x 64 pixel tiles; wave w owns tile rows 2w, 2w+1 and keeps nine
 // [32 ci x 32 n'] accumulators (one per kh).  Each wave writes its own slab [9][32][32];
 // k_conv9_wgrad_reduce sums slabs in a fixed order and un-folds n' = (8-kw)*3 + co.
-__global__ void __launch_bounds__(256) k_conv9x9_wgrad_mfma(Conv9Args a) {
+__global__ void __launch_bounds__(256, 2) k_conv9x9_wgrad_mfma(Conv9Args a) {
     DASR_DYN_SMEM(smem);
     float* sX = (float*)smem;                         // [8][64][32]
     float* sDy = sX + C9_TH * C9_TQ * 32;             // [16][DYW]
@@ -212,16 +250,37 @@ __global__ void __launch_bounds__(256) k_conv9x9_wgrad_mfma(Conv9Args a) {
     for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int x0 = tx * C9_TQ, y0 = ty * C9_TH;
-        __syncthreads();
-        for (int idx = tid; idx < C9_TH * C9_TQ * 8; idx += 256) {
-            int c4 = idx & 7, pix = idx >> 3;
-            int gy = y0 + pix / C9_TQ, gx = x0 + pix % C9_TQ;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < a.H && gx < a.W)
-                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
-            *(float4*)(sX + pix * 32 + 4 * c4) = v;
+        {   // x tile in four batches of four float4 per thread (144 accumulator registers are live), dy in one
+            float vdy[C9_NDY];
+            float4 vx[4];
+            auto ldx = [&](int u) {
+                const int idx = tid + 256 * u;
+                const int c4 = idx & 7, pix = idx >> 3;
+                const int gy = y0 + pix / C9_TQ, gx = x0 + pix % C9_TQ;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy < a.H && gx < a.W)
+                    v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
+                return v;
+            };
+            auto stx = [&](int u, float4 v) {
+                const int idx = tid + 256 * u;
+                *(float4*)(sX + (idx >> 3) * 32 + 4 * (idx & 7)) = v;
+            };
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vx[u] = ldx(u);
+            c9_load_dy(a, vdy, b, y0, x0, tid);
+            __syncthreads();                         // every wave is done with the previous tile
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stx(u, vx[u]);
+            c9_store_dy(sDy, vdy, tid);
+#pragma unroll
+            for (int bt = 1; bt < 4; ++bt) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vx[u] = ldx(4 * bt + u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) stx(4 * bt + u, vx[u]);
+            }
         }
-        c9_stage_dy(a, sDy, b, y0, x0, tid);
         __syncthreads();
 #pragma unroll 2
         for (int s = 0; s < 2 * C9_TQ / 2; ++s) {       // this wave's 2 rows x 64 columns, two pixels per step

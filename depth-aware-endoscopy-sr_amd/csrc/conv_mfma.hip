@@ -366,7 +366,7 @@ struct WgradArgs {
 };
 
 template <int MT, int NTW>
-__global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
+__global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_mfma(WgradArgs a) {
     DASR_DYN_SMEM(smem);
     constexpr int CIG = 32 * MT, COG = 32 * NTW;
     constexpr int WG_TH = wg_th(MT, NTW);
@@ -393,22 +393,52 @@ __global__ void __launch_bounds__(256) k_conv3x3_wgrad_mfma(WgradArgs a) {
     for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int x0 = tx * WG_TW, y0 = ty * WG_TH;
-        __syncthreads();
-        for (int idx = tid; idx < (WG_TH + 2) * (WG_TW + 2) * (CIG / 4); idx += 256) {
-            int c4 = idx % (CIG / 4), pix = idx / (CIG / 4);
-            int gy = y0 + pix / (WG_TW + 2) - 1, gx = x0 + pix % (WG_TW + 2) - 1;
+        // Stage the tile: ALL global loads of a thread are issued before the first LDS write (a "load; wait; write"
+        // loop is a chain of ~13 dependent L2/HBM round trips per tile - measured 10 us of a 25 us tile).  They are
+        // issued before the barrier, so their latency also covers the wait for the slowest wave of the last tile.
+        constexpr int NX = (WG_TH + 2) * (WG_TW + 2) * (CIG / 4), NXI = (NX + 255) / 256;
+        constexpr int ND = WG_TH * WG_TW * (COG / 4), NDI = (ND + 255) / 256;
+        // the 64x64 block already holds 144 accumulator registers: its x loads go in two batches (256-VGPR budget)
+        constexpr int XA = MT * NTW == 4 ? 4 : NXI;
+        float4 vx[XA > NXI - XA ? XA : NXI - XA], vd[NDI];
+        auto ldx = [&](int u) {
+            const int idx = tid + 256 * u;
+            const int c4 = idx % (CIG / 4), pix = idx / (CIG / 4);
+            const int gy = y0 + pix / (WG_TW + 2) - 1, gx = x0 + pix % (WG_TW + 2) - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            if (idx < NX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                 v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
-            *(float4*)(sX + pix * CIG + 4 * c4) = v;
-        }
-        for (int idx = tid; idx < WG_TH * WG_TW * (COG / 4); idx += 256) {
-            int c4 = idx % (COG / 4), pix = idx / (COG / 4);
-            int gy = y0 + pix / WG_TW, gx = x0 + pix % WG_TW;
+            return v;
+        };
+        auto stx = [&](int u, float4 v) {
+            const int idx = tid + 256 * u;
+            if (idx < NX) *(float4*)(sX + (idx / (CIG / 4)) * CIG + 4 * (idx % (CIG / 4))) = v;
+        };
+#pragma unroll
+        for (int u = 0; u < XA; ++u) vx[u] = ldx(u);
+#pragma unroll
+        for (int u = 0; u < NDI; ++u) {
+            const int idx = tid + 256 * u;
+            const int c4 = idx % (COG / 4), pix = idx / (COG / 4);
+            const int gy = y0 + pix / WG_TW, gx = x0 + pix % WG_TW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < a.H && gx < a.W)
+            if (idx < ND && gy < a.H && gx < a.W)
                 v = *(const float4*)(a.dy + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * c4);
-            *(float4*)(sD + pix * COG + 4 * c4) = v;
+            vd[u] = v;
+        }
+        __syncthreads();                        // every wave is done with the previous tile
+#pragma unroll
+        for (int u = 0; u < XA; ++u) stx(u, vx[u]);
+#pragma unroll
+        for (int u = 0; u < NDI; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < ND) *(float4*)(sD + (idx / (COG / 4)) * COG + 4 * (idx % (COG / 4))) = vd[u];
+        }
+        if (XA < NXI) {
+#pragma unroll
+            for (int u = XA; u < NXI; ++u) vx[u - XA] = ldx(u);
+#pragma unroll
+            for (int u = XA; u < NXI; ++u) stx(u, vx[u - XA]);
         }
         __syncthreads();
         if (do_bias) {                          // bias gradient: column sums of the staged dy tile

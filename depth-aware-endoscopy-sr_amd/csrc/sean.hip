@@ -343,34 +343,55 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 // or a pixel no mask claims); float4 copies, 16 threads per 64-channel row.
 // With bias_g / bias_b given, the conv biases are folded into the tap-0 rows (bias + row, the first addition of the
 // gather's fixed summation order, so the result is bit-identical to adding the bias first).
+template <int NB = 8>
 __device__ __forceinline__ void sean_stage_D(const SeanGeom& g, const float* __restrict__ D, float* sD, int b, int c0,
                                              const float* __restrict__ bias_g = nullptr,
                                              const float* __restrict__ bias_b = nullptr) {
-    const int K1 = g.K + 1;
-    const int q = threadIdx.x & 15;
+    const int K1 = g.K + 1, rows = 18 * K1;
+    const int q = threadIdx.x & 15, rstep = blockDim.x >> 4;
     const bool inC = c0 + 4 * q + 3 < g.C;
-    for (int r = threadIdx.x >> 4; r < 18 * K1; r += blockDim.x >> 4) {
-        const int st = r / K1, k = r - st * K1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < g.K) {
-            const float* src = D + (((size_t)b * 18 + st) * g.K + k) * g.C + c0 + 4 * q;
-            if (inC) v = *(const float4*)src;
+    // batches of NB rows per thread: the loads of a batch are all issued before its first LDS write (one L2 round
+    // trip per batch instead of one per row - a "load; wait; write" loop is a chain of dependent round trips)
+    for (int r0 = threadIdx.x >> 4; r0 < rows; r0 += NB * rstep) {
+        float4 v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int r = r0 + u * rstep;
+            const int st = r / K1, k = r - st * K1;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && k < g.K && inC) v[u] = *(const float4*)(D + (((size_t)b * 18 + st) * g.K + k) * g.C + c0 + 4 * q);
         }
-        if (bias_g && inC && (st == 0 || st == 9)) {
-            const float4 bv = *(const float4*)((st == 0 ? bias_g : bias_b) + c0 + 4 * q);
-            v = make_float4(bv.x + v.x, bv.y + v.y, bv.z + v.z, bv.w + v.w);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int r = r0 + u * rstep;
+            if (r >= rows) continue;
+            const int st = r / K1;
+            if (bias_g && inC && (st == 0 || st == 9)) {
+                const float4 bv = *(const float4*)((st == 0 ? bias_g : bias_b) + c0 + 4 * q);
+                v[u] = make_float4(bv.x + v[u].x, bv.y + v[u].y, bv.z + v[u].z, bv.w + v[u].w);
+            }
+            *(float4*)(sD + r * 64 + 4 * q) = v[u];
         }
-        *(float4*)(sD + r * 64 + 4 * q) = v;
     }
 }
-// region tile with a 1-pixel halo; TH rows x SF_TW columns
+// region tile with a 1-pixel halo; TH rows x SF_TW columns; two bytes per thread and pass, loads before stores
 __device__ __forceinline__ void sean_stage_R(const SeanGeom& g, const unsigned char* __restrict__ region,
                                              unsigned char* sR, int b, int y0, int x0, int TH) {
-    for (int i = threadIdx.x; i < (TH + 2) * (SF_TW + 2); i += blockDim.x) {
-        int gy = y0 + i / (SF_TW + 2) - 1, gx = x0 + i % (SF_TW + 2) - 1;
-        unsigned char v = (unsigned char)g.K;
-        if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = region[((size_t)b * g.H + gy) * g.W + gx];
-        sR[i] = v;
+    const int n = (TH + 2) * (SF_TW + 2);
+    for (int i0 = threadIdx.x; i0 < n; i0 += 2 * blockDim.x) {
+        unsigned char v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u * blockDim.x;
+            const int gy = y0 + i / (SF_TW + 2) - 1, gx = x0 + i % (SF_TW + 2) - 1;
+            v[u] = (unsigned char)g.K;
+            if (i < n && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v[u] = region[((size_t)b * g.H + gy) * g.W + gx];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < n) sR[i] = v[u];
+        }
     }
 }
 // gamma1 / beta1 of tile-local pixel (ly, lx): 9 row gathers from sD each (same summation order as the general
@@ -484,7 +505,7 @@ __global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const fl
         const int b = T.b, y0 = T.y0, x0 = T.x0;
         __syncthreads();                                   // previous tile is done with sR (and sD)
         if (b != cur_b) {
-            sean_stage_D(g, D, sD, b, c0, bias_g, bias_b);
+            sean_stage_D<HAS_RES ? 2 : 4>(g, D, sD, b, c0, bias_g, bias_b);
             cur_b = b;
             if (live) {
                 mu = *(const float4*)(mean + (size_t)b * g.C + c);
