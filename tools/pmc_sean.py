@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of k_sean_fwd_onehot from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; --output-format
+csv) over `tools/bench_ops.py --batch B --only sean` -> profiles/sean_fwd_pmc.json (read by bench.py for roofline.traffic).
+Usage: python tools/pmc_sean.py <fetch dir> <write dir> [B]"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def load(d, ctr):
+    agg = collections.defaultdict(list)
+    for path in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == ctr and "k_sean_fwd_onehot" in r["Kernel_Name"]:
+                agg["res" if "true>" in r["Kernel_Name"].split("(")[0] else "nores"].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+H, W, C, K = 128, 160, 64, 10
+px = B * H * W
+hbm = {k: 2 * fetch[k] * 1024 + write[k] * 1024 for k in fetch}
+out = {
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/bench_ops.py --batch %d "
+              "--only sean, kernel k_sean_fwd_onehot<relu, residual>, MI355X" % B,
+    "units_note": "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) "
+                  "coalesced streaming read (MI355X_MICROARCH.md, HBM), so fetch bytes = 2 * FETCH_SIZE * 1024; "
+                  "WRITE_SIZE is exact (the residual variant's extra 7 MB are its register spills in the tile prologue)",
+    "B": B, "H": H, "W": W, "C": C, "K": K,
+    "fetch_kib_no_residual": fetch["nores"], "fetch_kib_residual": fetch["res"],
+    "write_kib_no_residual": write["nores"], "write_kib_residual": write["res"],
+    "hbm_bytes_per_launch_no_residual": hbm["nores"], "hbm_bytes_per_launch_residual": hbm["res"],
+    "hbm_bytes_per_launch": (hbm["nores"] + hbm["res"]) / 2,
+    "algorithmic_bytes_per_launch": (px * (16 * C + 4 * K) + px * (20 * C + 4 * K)) / 2,
+}
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "sean_fwd_pmc.json")
+json.dump(out, open(path, "w"), indent=1)
+print(json.dumps(out, indent=1))
