@@ -131,12 +131,12 @@ class _Encoder(nn.Module):
 # ---------------------------------------------------------------------------------------------
 class _DepthNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, inp, depth_map, depth_mask, *params):
+    def forward(ctx, net, inp, depth_map, depth_mask, region, *params):
         tape = Tape(enabled=True)
         pvars = [Var(p.detach(), p.requires_grad, name) for (name, _), p in zip(net._param_items, params)]
         P = {v.name: v for v in pvars}
         out = graph.depthnet_forward(tape, P, net.cfg, net._consts(inp.device), inp.detach().contiguous(),
-                                     depth_map.detach().contiguous(), depth_mask.detach().contiguous())
+                                     depth_map.detach().contiguous(), depth_mask.detach().contiguous(), region)
         ctx.tape, ctx.pvars, ctx.out = tape, pvars, out
         return out.data
 
@@ -149,7 +149,7 @@ class _DepthNetFunction(torch.autograd.Function):
         tape.backward()
         ctx.tape = None
         grads = tuple(v.grad for v in pvars)
-        return (None, None, None, None) + grads
+        return (None, None, None, None, None) + grads
 
 
 class DepthNet(nn.Module):
@@ -215,10 +215,19 @@ class DepthNet(nn.Module):
                 raise TypeError("DepthNet: %s must be float32" % nm)
         if input.dim() != 4 or depthMap.dim() != 4 or depthMask.dim() != 4:
             raise ValueError("DepthNet: expected 4-D NCHW tensors")
+        # masks prepared on the device (dasr_amd.prep.depth_to_masks) carry their region bytes: no compression pass,
+        # no host read-back of the one-hot flag
+        region = getattr(depthMask, "_dasr_region", None)
+        if region is not None and tuple(region.shape) != (depthMask.shape[0],) + tuple(depthMask.shape[2:]):
+            region = None
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _DepthNetFunction.apply(self, input, depthMap, depthMask, *params)
+            return _DepthNetFunction.apply(self, input, depthMap, depthMask, region, *params)
         tape = Tape(enabled=False)
+        if not self.training:                 # netG.eval() + no_grad (F_model_depthCond.test): fold weights once
+            if not hasattr(self, "_fold_cache"):
+                object.__setattr__(self, "_fold_cache", {})
+            tape.fold_cache = self._fold_cache
         P = {name: Var(p.detach(), False, name) for name, p in items}
         out = graph.depthnet_forward(tape, P, self.cfg, self._consts(input.device), input.detach().contiguous(),
-                                     depthMap.detach().contiguous(), depthMask.detach().contiguous())
+                                     depthMap.detach().contiguous(), depthMask.detach().contiguous(), region)
         return out.data

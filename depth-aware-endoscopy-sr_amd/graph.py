@@ -41,9 +41,27 @@ def _side_stream(device, which="branch"):
 # ---------------------------------------------------------------------------------------------
 # recorded primitives
 # ---------------------------------------------------------------------------------------------
+def _folded(tape, key, tensors, make):
+    """Inference-time weight folding: with the tape off and a cache attached
+    (DepthNet keeps one per module), a packed kernel - weight_norm g*v/||v|| folded in, HWIO + per-tap transpose - is
+    built once and reused until one of its source parameters changes (torch's version counters)."""
+    cache = tape.fold_cache
+    if tape.enabled or cache is None or key is None:
+        return make()
+    ver = tuple((t.data_ptr(), t._version) for t in tensors)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    val = make()
+    cache[key] = (ver, val)
+    return val
+
+
 def pack(tape, v, g=None, transposed=False):
     """weight_norm (if g) + OIHW -> HWIO."""
-    w, inv = ops.weight_pack(v.data, g.data if g is not None else None, transposed)
+    srcs = [v.data] + ([g.data] if g is not None else [])
+    w, inv = _folded(tape, ("pack", v.name) if v.name else None, srcs,
+                     lambda: ops.weight_pack(v.data, g.data if g is not None else None, transposed))
     out = Var(w, v.requires_grad or (g is not None and g.requires_grad))
 
     def bwd():
@@ -66,9 +84,14 @@ def pack_pair(tape, va, vb):
     """Two plain OIHW kernels with equal Cin side by side along Cout (mlp_gamma_o | mlp_beta_o)."""
     Oa, I, KH, KW = va.data.shape
     Ob = vb.data.shape[0]
-    w = ops.empty((2, KH, KW, I, Oa + Ob), va.data)
-    ops.weight_pack(va.data, None, False, out=w, o_off=0)
-    ops.weight_pack(vb.data, None, False, out=w, o_off=Oa)
+
+    def make():
+        w = ops.empty((2, KH, KW, I, Oa + Ob), va.data)
+        ops.weight_pack(va.data, None, False, out=w, o_off=0)
+        ops.weight_pack(vb.data, None, False, out=w, o_off=Oa)
+        return w
+
+    w = _folded(tape, ("pair", va.name) if va.name else None, [va.data, vb.data], make)
     out = Var(w, va.requires_grad or vb.requires_grad)
 
     def bwd():
@@ -89,9 +112,14 @@ def pack_pair(tape, va, vb):
 
 def bias_pair(tape, ba, bb):
     na, nb = ba.data.numel(), bb.data.numel()
-    buf = ops.empty((na + nb,), ba.data)
-    ops.copy_(buf[:na], ba.data)
-    ops.copy_(buf[na:], bb.data)
+
+    def make():
+        buf = ops.empty((na + nb,), ba.data)
+        ops.copy_(buf[:na], ba.data)
+        ops.copy_(buf[na:], bb.data)
+        return buf
+
+    buf = _folded(tape, ("bias", ba.name) if ba.name else None, [ba.data, bb.data], make)
     out = Var(buf, ba.requires_grad or bb.requires_grad)
 
     def bwd():
@@ -282,8 +310,11 @@ class MaskPack:
     (one region byte per pixel and a device-side "not one-hot" flag, dasr_mask_compress)."""
     __slots__ = ("planes", "region", "flag")
 
-    def __init__(self, planes):
+    def __init__(self, planes, region=None):
         self.planes = planes
+        if region is not None:               # prepared on the device (prep.depth_to_masks): one-hot by construction
+            self.region, self.flag = region, None
+            return
         region, flag = ops.mask_compress(planes)
         # one 4-byte read-back per forward: lets every SEAN call launch exactly one kernel.  (Pass the device flag
         # through instead - both kernels launched, decision on the device - if the forward must not synchronise.)
@@ -382,9 +413,10 @@ def upscale(tape, P, name, x, r, second):
     return x
 
 
-def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask):
+def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=None):
     """DepthNet.forward (sftmd_arch.py:912-950). ``inp`` [B,3,H,W], ``depth_map`` [B,1,h,w],
-    ``depth_mask`` [B,K,h,w] are the caller's NCHW tensors; returns (out NCHW tensor, out Var)."""
+    ``depth_mask`` [B,K,h,w] are the caller's NCHW tensors; returns (out NCHW tensor, out Var).
+    ``region``: the masks' region bytes [B,h,w] when they were prepared on the device (prep.depth_to_masks)."""
     plan = block_plan(cfg)
     nb, scale = cfg["nb"], cfg["scale"]
     B = inp.shape[0]
@@ -401,7 +433,7 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask):
                   transposed=True, act=L)
         e5 = conv(tape, e4, _wn(tape, P, "encoder.layer5"), P["encoder.layer5.bias"], stride=2)
         st = region_pool(tape, e5, depth_mask)
-    mask_pack = MaskPack(depth_mask) if st is not None else None
+    mask_pack = MaskPack(depth_mask, region) if st is not None else None
     # head (:920)
     h1 = conv(tape, e1, _wn(tape, P, "head.0"), P["head.0.bias"], act=L)
     fea_bef = conv(tape, h1, _wn(tape, P, "head.2"), P["head.2.bias"], act=L)

@@ -62,9 +62,11 @@ def fused_losses(sr, hr, mask_list, trainable_weight, pixel_weight, dynamic_weig
     h, w = mask_list.shape[2:]
     if H % h or W % w or H // h != W // w:
         return None
-    region, flag = ops.mask_compress(mask_list.contiguous())
-    if int(flag.item()) != 0:
-        return None
+    region = getattr(mask_list, "_dasr_region", None)        # prepared on the device: one-hot by construction
+    if region is None or tuple(region.shape) != (mask_list.shape[0], h, w):
+        region, flag = ops.mask_compress(mask_list.contiguous())
+        if int(flag.item()) != 0:
+            return None
     K = mask_list.shape[1]
     sums = _RegionSums.apply(sr, hr, region, K)
     num, den, l1 = sums[:K], sums[K:2 * K].detach(), sums[2 * K]
@@ -205,6 +207,51 @@ class Trainer:
         sr = self.net(lq, depth, masks)
         self.net.train()
         return sr
+
+
+# ---- checkpoint interop (codes/models/base_model.py:77-119) --------------------------------
+def save_network(net, path):
+    """base_model.save_network: the module's state_dict (reference key names) with CPU tensors."""
+    net = getattr(net, "module", net)
+    torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, path)
+
+
+def load_network(path, net, strict=True):
+    """base_model.load_network: accepts the authors' `*_G.pth` files (a leading 'module.' from DataParallel
+    checkpoints is stripped); strict key matching as in the reference."""
+    net = getattr(net, "module", net)
+    loaded = torch.load(path, map_location="cpu")
+    clean = {(k[7:] if k.startswith("module.") else k): v for k, v in loaded.items()}
+    return net.load_state_dict(clean, strict=strict)
+
+
+def _save_training_state(trainer, path, epoch=0):
+    """base_model.save_training_state: {'epoch','iter','schedulers','optimizers'}; the scheduler here is stateless
+    given the step, so its entry holds the step and its constants.  'loss_weights' is an addition: the reference keeps
+    the 10 dynamic-loss weights outside netG and does not checkpoint them at all."""
+    state = {"epoch": epoch, "iter": trainer.step_count,
+             "schedulers": [dict(last_epoch=trainer.step_count, base_lr=trainer.base_lr, **trainer.sched)],
+             "optimizers": [trainer.optimizer.state_dict()],
+             "loss_weights": trainer.dynamic_loss.trainable_weight.detach().cpu()}
+    torch.save(state, path)
+
+
+def _resume_training(trainer, state):
+    """base_model.resume_training."""
+    if isinstance(state, str):
+        state = torch.load(state, map_location="cpu")
+    assert len(state["optimizers"]) == 1, "Wrong lengths of optimizers"
+    assert len(state["schedulers"]) == 1, "Wrong lengths of schedulers"
+    trainer.optimizer.load_state_dict(state["optimizers"][0])
+    trainer.step_count = int(state["schedulers"][0]["last_epoch"])
+    if "loss_weights" in state:
+        with torch.no_grad():
+            trainer.dynamic_loss.trainable_weight.copy_(state["loss_weights"].to(trainer.dynamic_loss.trainable_weight.device))
+    return state.get("epoch", 0), state.get("iter", trainer.step_count)
+
+
+Trainer.save_training_state = _save_training_state
+Trainer.resume_training = _resume_training
 
 
 def calculate_psnr(img1, img2):

@@ -263,6 +263,22 @@ def mask_compress(mask):
     return region, flag
 
 
+def depth_to_masks(depth, num_masks=10, fixed_edges=None, want_planes=True):
+    """Device getDepthMask (dasr_depth_to_masks): depth [B,1,h,w] or [B,h,w] -> (planes [B,K,h,w] float or None,
+    region bytes [B,h,w]).  fixed_edges: None (per-sample min/max range) or K+1 float32 device values."""
+    h, w = depth.shape[-2:]
+    B = depth.numel() // (h * w)
+    d = depth.contiguous()
+    planes = torch.empty((B, num_masks, h, w), dtype=torch.float32, device=d.device) if want_planes else None
+    region = torch.empty((B, h, w), dtype=torch.uint8, device=d.device)
+    nbytes = int(_lib.get().dasr_depth_to_masks_workspace(B, h * w))
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=d.device)
+    _call("dasr_depth_to_masks", _p(d), _p(fixed_edges, True) if fixed_edges is not None else None,
+          _p(planes) if planes is not None else None, _lib.ptr(region, dtype=torch.uint8), _p(ws), nbytes, B, h * w,
+          num_masks)
+    return planes, region
+
+
 def _rf(region, flag):
     if region is None:
         return None, None

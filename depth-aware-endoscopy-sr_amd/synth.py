@@ -52,15 +52,18 @@ def depth_to_masks(depth: torch.Tensor, num_masks: int = 10, fixed_range: bool =
     """
     d = depth.reshape(depth.shape[-2], depth.shape[-1]).to(torch.float32)
     if fixed_range:
-        lo = torch.tensor(0.0)
-        hi = torch.tensor(1.0)
+        # the reference sets min/max to the Python ints 0 and 1: edges are Python doubles, and torch compares the
+        # float32 map against each of them rounded to float32
+        interval = (1 - 0) / num_masks
+        edges = torch.tensor([0 + interval * i for i in range(num_masks + 1)], dtype=torch.float64).to(torch.float32)
+        starts, ends = edges[:-1].view(-1, 1, 1), edges[1:].view(-1, 1, 1)
     else:
         lo = d.min()
         hi = d.max()
-    delta = (hi - lo) / num_masks
-    idx = torch.arange(num_masks, dtype=torch.float32)
-    starts = (lo + delta * idx).view(-1, 1, 1)
-    ends = (lo + delta * (idx + 1.0)).view(-1, 1, 1)
+        delta = (hi - lo) / num_masks
+        idx = torch.arange(num_masks, dtype=torch.float32)
+        starts = (lo + delta * idx).view(-1, 1, 1)
+        ends = (lo + delta * (idx + 1.0)).view(-1, 1, 1)
     return ((d.unsqueeze(0) >= starts) & (d.unsqueeze(0) < ends)).to(torch.float32)
 
 

@@ -39,6 +39,7 @@ class Tape:
         self.nodes = []
         self._stream = None
         self.side_streams = []
+        self.fold_cache = None      # inference only: {param name: (versions, packed tensor)}, see graph._folded
 
     def record(self, fn):
         if self.enabled:

@@ -200,6 +200,21 @@ int dasr_region_pool_fwd(const float* feat, const float* mask, float* maskr, flo
 int dasr_region_pool_bwd(const float* dout, const float* maskr, const float* area, float* dfeat, int B, int K, int L,
                          int h, int w, void* stream);
 
+/* ---- device-side input preparation ------------------------------------------------------
+ * Replaces LQGTker_Depth_dataset.getDepthMask (codes/data/LQGTker_Depth_dataset.py:204-225) + the host-side
+ * stacking of the K float planes (:155-158,196): per sample, K equal-width half-open bins over the map's own
+ * [min, max] (float32 arithmetic as torch evaluates it: interval = (max-min)/K, edge_i = min + interval*i); a
+ * pixel equal to the maximum belongs to no bin.  depth: [B,HW] float32.  Outputs (either may be NULL, not both):
+ * masks NCHW [B,K,HW] of 0/1 floats (what DepthNet.forward takes) and region bytes [B,HW] (k, or K for "no bin":
+ * what the one-hot SEAN / loss kernels read - identical to dasr_mask_compress of those planes).
+ * fixed_edges: NULL for the data-dependent range (depthFixedRange: false, every shipped yml); else K+1 DEVICE
+ * floats holding the edges of the fixed [0,1] range (the reference computes those in Python doubles; the host
+ * wrapper passes them rounded to float32, which is what torch compares against).
+ * workspace: dasr_depth_to_masks_workspace() bytes (per-chunk minima / maxima). */
+size_t dasr_depth_to_masks_workspace(int B, int HW);
+int dasr_depth_to_masks(const float* depth, const float* fixed_edges, float* masks, unsigned char* region,
+                        void* workspace, size_t workspace_bytes, int B, int HW, int K, void* stream);
+
 /* ---- harness losses in one pass (one-hot masks only) -------------------------------------
  * nn.L1Loss + dynamic_weight_mask_loss('smoothl1') (F_model_depthCond.py:164,188-190; mask_loss.py:64-90) need, per
  * depth region k, sum smooth_l1(m_k*sr, m_k*hr) and sum m_k (masks nearest-upsampled to HR), and sum |sr-hr|.

@@ -218,4 +218,13 @@ for step in range(1, 80001):
     if step in probe:
         lrs[str(step)] = optim.param_groups[0]["lr"]
 json.dump(lrs, open(os.path.join(OUT, "lr_schedule.json"), "w"), indent=1)
+# ---------------------------------------------------------------- 8. SSIM of the validation loop (pytorch_ssim, train.py:240)
+import pytorch_ssim  # reference
+from tests.golden_cases import ssim_inputs
+vals = {}
+for name, (a, b) in ssim_inputs().items():
+    vals[name + ".mean"] = float(pytorch_ssim.ssim(a, b))
+    vals[name + ".per_image"] = pytorch_ssim.ssim(a, b, size_average=False).numpy()
+save("ssim", **vals)
+
 print("done")

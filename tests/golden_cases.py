@@ -105,3 +105,18 @@ def digest_close(got, want, rtol, atol):
     scale = max(1e-30, float(np.abs(want).max()))
     err = float(np.abs(d - want).max())
     return err <= atol + rtol * scale, err, scale
+
+
+# ---- SSIM (validation loop) -----------------------------------------------------------------
+def ssim_inputs():
+    """RNG-free [0,1] image pairs: smooth + hashed texture, the second a perturbed copy of the first."""
+    out = {}
+    for name, (B, H, W) in (("small", (2, 24, 31)), ("hr", (1, 96, 120))):
+        n = B * 3 * H * W
+        base = 0.5 + 0.35 * _wave((B, 3, H, W), 0.0131, 0.3, torch.float32) * _wave((B, 3, H, W), 0.00071, 1.1, torch.float32)
+        tex = synth.hash_uniform(n, "ssim." + name).reshape(B, 3, H, W).to(torch.float32)
+        a = (base + 0.1 * (tex - 0.5)).clamp(0, 1)
+        b = (a + 0.08 * (synth.hash_uniform(n, "ssim.noise." + name).reshape(B, 3, H, W).to(torch.float32) - 0.5)).clamp(0, 1)
+        out[name] = (a, b)
+    out["identical"] = (out["small"][0], out["small"][0].clone())
+    return out

@@ -541,3 +541,146 @@ def check_full_size_x8(device):
     # profiles/r01_full_size_fp64_diagnostic.txt) - ReLU / clamp decisions flip on ~1e-7 differences.
     assert rel <= 3e-2, rel
     return dict(max_err=err, dpsnr=dpsnr, psnr_vs_ref=psnr_vs_ref, grad_rel_l2=rel)
+
+
+def check_depth_prep(device):
+    """dasr_depth_to_masks (prep.hip) against the host restatement of getDepthMask (synth.depth_to_masks,
+    LQGTker_Depth_dataset.py:204-225): planes and region bytes bit-exact, incl. the pixel(s) equal to the maximum
+    (no bin), a constant map (every bin empty), a map with values outside [0,1) in fixed-range mode; the region
+    bytes equal dasr_mask_compress of the planes; a net fed with prepared masks returns the same bits."""
+    from dasr_amd import prep
+    K = 10
+    maps = []
+    for i, (h, w) in enumerate(((16, 20), (33, 47), (128, 160))):
+        _, _, dm, _ = synth.seeded_batch(3 * i, 2, h, w, 1, K)
+        maps.append(dm)
+    g = torch.Generator().manual_seed(5)
+    maps.append(torch.rand(2, 1, 19, 23, generator=g) * 1.4 - 0.2)                  # outside [0,1) too
+    maps.append(torch.full((1, 1, 8, 12), 3.25))                                     # constant: all bins empty
+    maps.append((torch.arange(2 * 24 * 40, dtype=torch.float32) % 11).reshape(2, 1, 24, 40) / 10.0)   # exact edges
+    n_nobin = 0
+    for dm in maps:
+        for fixed in (False, True):
+            want = torch.stack([synth.depth_to_masks(dm[b], K, fixed) for b in range(dm.shape[0])])
+            got = prep.depth_to_masks(dm.to(device), K, fixed)
+            assert got.shape == want.shape and torch.equal(got.cpu(), want), ("planes", tuple(dm.shape), fixed)
+            region = got._dasr_region.cpu()
+            idx = torch.where(want.sum(1) > 0, want.argmax(1), torch.full_like(want.argmax(1), K)).to(torch.uint8)
+            assert torch.equal(region, idx), ("region", tuple(dm.shape), fixed)
+            r2, flag = ops.mask_compress(got)
+            assert int(flag.item()) == 0 and torch.equal(r2.cpu(), region)
+            assert torch.equal(prep.depth_to_region(dm.to(device), K, fixed).cpu(), region)
+            n_nobin += int((region == K).sum())
+    assert n_nobin > 0
+    # the net: prepared masks (region bytes attached) vs plain float planes
+    case = dict(name="prep", scale=4, which=[0, 1], L=32, nb=4, B=2, H=12, W=16)
+    net, cfg = build_net(case, device)
+    lq, gt, dm, mk = [t.to(device) for t in synth.seeded_batch(0, 2, 12, 16, 4)]
+    mk2 = prep.depth_to_masks(dm, K)
+    assert torch.equal(mk2, mk)
+    with torch.no_grad():
+        a = net(lq, dm, mk)
+        b = net(lq, dm, mk2)
+    assert torch.equal(a, b)
+    return dict(no_bin_pixels=n_nobin)
+
+
+def check_validation_and_folding(device):
+    """validate.validate (train.py:219-262) on two frames: the eval/no_grad forward equals the training-mode
+    forward bit for bit, folded weights are reused (same tensors on the second call) and refreshed when a
+    parameter changes; PSNR/SSIM equal the metrics computed from the oracle's output."""
+    from dasr_amd import validate
+    case = dict(name="val", scale=4, which=[0, 1], L=32, nb=4, B=1, H=12, W=16)
+    net, cfg = build_net(case, device)
+    frames = []
+    for i in range(2):
+        lq, gt, dm, mk = [t.to(device) for t in synth.seeded_batch(i, 1, 12, 16, 4)]
+        frames.append((lq, gt, dm, mk))
+    lq, gt, dm, mk = frames[0]
+    with torch.no_grad():
+        ref_out = net(lq, dm, mk)                       # training mode, no folding
+    assert not hasattr(net, "_fold_cache") or not net._fold_cache
+    out1 = validate.test(net, lq, dm, mk)
+    assert net.training and torch.equal(out1, ref_out)
+    n_folded = len(net._fold_cache)
+    assert n_folded > 10
+    ids = {k: id(v[1]) for k, v in net._fold_cache.items()}
+    out2 = validate.test(net, lq, dm, mk)
+    assert torch.equal(out2, ref_out) and {k: id(v[1]) for k, v in net._fold_cache.items()} == ids
+    # a parameter update invalidates exactly the folded kernels built from it
+    with torch.no_grad():
+        net.get_parameter("conv_output.weight").mul_(1.5)
+        net.get_parameter("head.0.weight_g").mul_(0.5)
+    out3 = validate.test(net, lq, dm, mk)
+    with torch.no_grad():
+        fresh = net(lq, dm, mk)
+    assert torch.equal(out3, fresh) and not torch.equal(out3, ref_out)
+    changed = [k for k, v in net._fold_cache.items() if id(v[1]) != ids[k]]
+    assert sorted(k[1] for k in changed) == ["conv_output.weight", "head.0.weight_v"], changed
+    # metrics against the oracle's image
+    psnr, ssim_v, n = validate.validate(net, frames, cfg["scale"])
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ps = ss = 0.0
+    for lq, gt, dm, mk in frames:
+        o = O.depthnet_forward(sd, cfg, lq.cpu(), dm.cpu(), mk.cpu())
+        ss += float(validate.ssim(o, gt.cpu()))
+        a, b = validate.tensor2img(o[0]) / 255.0, validate.tensor2img(gt[0]) / 255.0
+        ps += validate.calculate_psnr(a[4:-4, 4:-4] * 255, b[4:-4, 4:-4] * 255)
+    assert n == 2 and abs(psnr - ps / 2) <= 1e-2 and abs(ssim_v - ss / 2) <= 1e-5, (psnr, ps / 2, ssim_v, ss / 2)
+    return dict(psnr=psnr, ssim=ssim_v, folded=n_folded)
+
+
+def check_checkpoint_interop(device, tmpdir):
+    """base_model.save_network / load_network / save_training_state / resume_training (base_model.py:77-119):
+    reference key names, a DataParallel-style 'module.' checkpoint, strict failures, and a resumed run that
+    continues where the original left off (bit-identically on the deterministic emulator)."""
+    from dasr_amd import harness
+    case = dict(name="ckpt", scale=2, which=[0, 1], L=16, nb=4, B=1, H=8, W=12)
+    net, cfg = build_net(case, device)
+    path = os.path.join(tmpdir, "100_G.pth")
+    harness.save_network(net, path)
+    loaded = torch.load(path)
+    assert list(loaded.keys()) == list(net.state_dict().keys()) and all(v.device.type == "cpu" for v in loaded.values())
+    torch.save({"module." + k: v for k, v in loaded.items()}, os.path.join(tmpdir, "dp_G.pth"))
+    net2, _ = build_net(case, device)
+    with torch.no_grad():
+        for p in net2.parameters():
+            p.add_(1.0)
+    harness.load_network(os.path.join(tmpdir, "dp_G.pth"), net2, strict=True)
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+    bad = dict(loaded)
+    bad.pop("conv_output.bias")
+    torch.save(bad, os.path.join(tmpdir, "bad_G.pth"))
+    try:
+        harness.load_network(os.path.join(tmpdir, "bad_G.pth"), net2, strict=True)
+        raise AssertionError("strict load of an incomplete checkpoint must fail")
+    except RuntimeError:
+        pass
+    # resume: 2 steps + save + 1 step  ==  load + 1 step
+    batch = [t.to(device) for t in synth.seeded_batch(0, 1, 8, 12, 2)]
+    tr = harness.Trainer(net)
+    for _ in range(2):
+        tr.optimize_parameters(*batch)
+    harness.save_network(net, os.path.join(tmpdir, "2_G.pth"))
+    tr.save_training_state(os.path.join(tmpdir, "2.state"), epoch=3)
+    tr.optimize_parameters(*batch)
+    want = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    want_w = tr.dynamic_loss.trainable_weight.detach().clone()
+    net3, _ = build_net(case, device)
+    harness.load_network(os.path.join(tmpdir, "2_G.pth"), net3)
+    tr3 = harness.Trainer(net3)
+    epoch, it = tr3.resume_training(os.path.join(tmpdir, "2.state"))
+    assert (epoch, it) == (3, 2) and tr3.step_count == 2
+    tr3.optimize_parameters(*batch)
+    # bit-identical on the (deterministic) emulator; on the GPU the bias / small-wgrad sums meet in float atomics, so
+    # two runs of the same step differ in the last bits of the gradient
+    exact = device == "cpu"
+    for k, v in net3.state_dict().items():
+        if exact:
+            assert torch.equal(v, want[k]), k
+        elif not any(z in k for z in ZERO_GRAD_KEYS):   # their gradient is rounding noise, which Adam turns into +-lr steps
+            assert torch.allclose(v, want[k], rtol=1e-4, atol=2e-6), (k, (v - want[k]).abs().max().item())
+    assert torch.allclose(tr3.dynamic_loss.trainable_weight.detach(), want_w, rtol=0 if exact else 1e-5, atol=0 if exact else 1e-6)
+    state = torch.load(os.path.join(tmpdir, "2.state"))
+    assert set(("epoch", "iter", "schedulers", "optimizers")) <= set(state.keys())
+    return dict(keys=len(loaded), resumed_iter=it)

@@ -82,3 +82,18 @@ def test_full_size_x8_vs_oracle():
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.gpu
+def test_depth_prep():
+    print(pc.check_depth_prep("cuda"))
+
+
+@pytest.mark.gpu
+def test_validation_and_folding():
+    print(pc.check_validation_and_folding("cuda"))
+
+
+@pytest.mark.gpu
+def test_checkpoint_interop(tmp_path):
+    print(pc.check_checkpoint_interop("cuda", str(tmp_path)))

@@ -67,3 +67,7 @@ def test_state_dict_roundtrip():
 
 def test_reference_assertion(emu):
     pc.check_reference_assertion("cpu")
+
+
+def test_depth_prep(emu):
+    print(pc.check_depth_prep("cpu"))
