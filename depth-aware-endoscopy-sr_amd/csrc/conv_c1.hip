@@ -6,32 +6,50 @@
 #include "dasr_common.h"
 #include "conv_kernels.h"
 
+// Both kernels walk image ROWS: a workgroup stages the three depth-map rows around row (b, y) in LDS (zero padded,
+// W + 2 floats each) and its threads - channel quad q = tid % nq, pixel lane pl = tid / nq - step through the row's
+// pixels with plain 32-bit increments.  (The first version derived (b, y, x) of every pixel from a flat 64-bit index -
+// three 64-bit divisions per pixel - and fetched the 9 taps with predicated global loads: VALU-bound at 1.7 TB/s.)
+#define C1_MAXW 4096
+__device__ __forceinline__ void c1_stage_rows(const float* __restrict__ x, float* sRow, int b, int y, int H, int W) {
+    const float* xb = x + (size_t)b * H * W;
+    for (int i = threadIdx.x; i < 3 * (W + 2); i += 256) {
+        const int r = i / (W + 2), c = i - r * (W + 2);
+        const int iy = y + r - 1, ix = c - 1;
+        sRow[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[(size_t)iy * W + ix] : 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
                                                         int H, int W, int Cout, int act) {
+    DASR_DYN_SMEM(smem);
+    float* sRow = (float*)smem;                    // [3][W+2]
     const int nq = Cout / 4;                       // channel quads
     const int q = threadIdx.x % nq, pl = threadIdx.x / nq, npl = 256 / nq;
     float4 wt[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wt[t] = *(const float4*)(w + (size_t)t * Cout + 4 * q);
     const float4 bv = bias ? *(const float4*)(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t npix = (size_t)B * H * W;
-    if (pl >= npl) return;
-    for (size_t p = (size_t)blockIdx.x * npl + pl; p < npix; p += (size_t)gridDim.x * npl) {
-        const int px = (int)(p % W), py = (int)((p / W) % H);
-        const size_t b = p / ((size_t)W * H);
-        const float* xb = x + b * (size_t)H * W;
-        float4 acc = bv;
+    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+        const int b = row / H, py = row - b * H;
+        __syncthreads();
+        c1_stage_rows(x, sRow, b, py, H, W);
+        __syncthreads();
+        if (pl >= npl) continue;
+        float* yrow = y + ((size_t)row * W) * Cout + 4 * q;
+        for (int px = pl; px < W; px += npl) {
+            float4 acc = bv;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
-            const float d = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[(size_t)iy * W + ix] : 0.f;
-            acc.x = fmaf(d, wt[t].x, acc.x); acc.y = fmaf(d, wt[t].y, acc.y);
-            acc.z = fmaf(d, wt[t].z, acc.z); acc.w = fmaf(d, wt[t].w, acc.w);
+            for (int t = 0; t < 9; ++t) {
+                const float d = sRow[(t / 3) * (W + 2) + px + t % 3];
+                acc.x = fmaf(d, wt[t].x, acc.x); acc.y = fmaf(d, wt[t].y, acc.y);
+                acc.z = fmaf(d, wt[t].z, acc.z); acc.w = fmaf(d, wt[t].w, acc.w);
+            }
+            acc.x = dasr_act(acc.x, act); acc.y = dasr_act(acc.y, act);
+            acc.z = dasr_act(acc.z, act); acc.w = dasr_act(acc.w, act);
+            *(float4*)(yrow + (size_t)px * Cout) = acc;
         }
-        acc.x = dasr_act(acc.x, act); acc.y = dasr_act(acc.y, act);
-        acc.z = dasr_act(acc.z, act); acc.w = dasr_act(acc.w, act);
-        *(float4*)(y + p * Cout + 4 * q) = acc;
     }
 }
 
@@ -42,50 +60,52 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restric
                                                           int act) {
     DASR_DYN_SMEM(smem);
     float* red = (float*)smem;                     // [256][40] partials
+    float* sRow = red + 256 * 40;                  // [3][W+2]
     const int nq = Cout / 4;
     const int q = threadIdx.x % nq, pl = threadIdx.x / nq, npl = 256 / nq;
     float4 acc[10];
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t npix = (size_t)B * H * W;
-    const size_t stride = (size_t)gridDim.x * npl;
-    if (pl < npl)
-        for (size_t p0 = (size_t)blockIdx.x * npl + pl; p0 < npix; p0 += 4 * stride) {
-            // four pixels per trip: all eight 16-byte loads are issued before the first is consumed
+    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+        const int b = row / H, py = row - b * H;
+        __syncthreads();
+        c1_stage_rows(x, sRow, b, py, H, W);
+        __syncthreads();
+        if (pl >= npl) continue;
+        const float* grow = dy + ((size_t)row * W) * Cout + 4 * q;
+        const float* arow = yact ? yact + ((size_t)row * W) * Cout + 4 * q : nullptr;
+        for (int px0 = pl; px0 < W; px0 += 4 * npl) {
+            // four pixels per trip: all eight 16-byte loads are issued before the first is consumed (clamped
+            // addresses, contributions of pixels past the row end are zeroed)
             float4 gq[4], yq[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const size_t p = p0 + u * stride;
-                gq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                yq[u] = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (p < npix) {
-                    gq[u] = *(const float4*)(dy + p * Cout + 4 * q);
-                    if (yact) yq[u] = *(const float4*)(yact + p * Cout + 4 * q);
-                }
+                const int px = px0 + u * npl < W ? px0 + u * npl : W - 1;
+                gq[u] = *(const float4*)(grow + (size_t)px * Cout);
+                yq[u] = arow ? *(const float4*)(arow + (size_t)px * Cout) : make_float4(1.f, 1.f, 1.f, 1.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const size_t p = p0 + u * stride;
-                if (p >= npix) continue;
-                const int px = (int)(p % W), py = (int)((p / W) % H);
-                const size_t b = p / ((size_t)W * H);
-                const float* xb = x + b * (size_t)H * W;
+                const int px = px0 + u * npl;
                 float4 g = gq[u];
-                if (yact) {
+                if (px >= W) g = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int pc = px < W ? px : W - 1;
+                if (arow) {
                     g.x *= dasr_act_grad_from_out(yq[u].x, act); g.y *= dasr_act_grad_from_out(yq[u].y, act);
                     g.z *= dasr_act_grad_from_out(yq[u].z, act); g.w *= dasr_act_grad_from_out(yq[u].w, act);
                 }
                 acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
-                    const float d = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[(size_t)iy * W + ix] : 0.f;
+                    const float d = sRow[(t / 3) * (W + 2) + pc + t % 3];
                     acc[t].x = fmaf(d, g.x, acc[t].x); acc[t].y = fmaf(d, g.y, acc[t].y);
                     acc[t].z = fmaf(d, g.z, acc[t].z); acc[t].w = fmaf(d, g.w, acc[t].w);
                 }
             }
         }
+    }
     // reduce over the pixel lanes of the workgroup, then one float atomic per output per workgroup
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 10; ++t) *(float4*)(red + (threadIdx.x * 10 + t) * 4) = acc[t];
     __syncthreads();
@@ -100,14 +120,13 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restric
 
 bool conv_c1_supported(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && g.Cin == 1 && (g.Cout % 4) == 0 &&
-           g.Cout <= 1024 && (256 % (g.Cout / 4)) == 0 && g.H == g.Ho && g.W == g.Wo;
+           g.Cout <= 1024 && (256 % (g.Cout / 4)) == 0 && g.H == g.Ho && g.W == g.Wo && g.W <= C1_MAXW;
 }
 int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream) {
-    size_t npix = (size_t)g.B * g.H * g.W;
-    int npl = 256 / (g.Cout / 4);
-    unsigned grid = dasr_cdiv(npix, npl);
-    if (grid > 256 * 16) grid = 256 * 16;
-    DASR_LAUNCH(k_conv3x3_c1_fwd, dim3(grid), dim3(256), 0, stream, x, w, bias, y, g.B, g.H, g.W, g.Cout, act);
+    unsigned grid = (unsigned)(g.B * g.H);
+    if (grid > 256 * 8) grid = 256 * 8;
+    DASR_LAUNCH(k_conv3x3_c1_fwd, dim3(grid), dim3(256), sizeof(float) * 3 * (g.W + 2), stream, x, w, bias, y, g.B, g.H,
+                g.W, g.Cout, act);
     DASR_RETURN_LAUNCH_STATUS();
 }
 // yact may be null (dy is already the gradient w.r.t. the convolution output)
@@ -116,7 +135,9 @@ int conv_c1_wgrad(const ConvGeom& g, const float* x, const float* dy, const floa
     hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * 9 * g.Cout, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     if (dbias && (e = hipMemsetAsync(dbias, 0, sizeof(float) * g.Cout, (hipStream_t)stream)) != hipSuccess) return (int)e;
-    DASR_LAUNCH(k_conv3x3_c1_wgrad, dim3(1024), dim3(256), sizeof(float) * 256 * 40, stream, x, dy, yact, dw, dbias, g.B,
-                g.H, g.W, g.Cout, act);
+    unsigned grid = (unsigned)(g.B * g.H);
+    if (grid > 512) grid = 512;         // two workgroups per CU; more only adds float atomics at the end (measured)
+    DASR_LAUNCH(k_conv3x3_c1_wgrad, dim3(grid), dim3(256), sizeof(float) * (256 * 40 + 3 * (g.W + 2)), stream, x, dy, yact,
+                dw, dbias, g.B, g.H, g.W, g.Cout, act);
     DASR_RETURN_LAUNCH_STATUS();
 }
