@@ -147,8 +147,12 @@ class _DepthNetFunction(torch.autograd.Function):
             raise RuntimeError("DepthNet: backward called twice on the same forward")
         out.grad = dout.contiguous()
         tape.backward()
-        ctx.tape = None
         grads = tuple(v.grad for v in pvars)
+        # drop every other reference to the gradient tensors: autograd's AccumulateGrad then adopts them as
+        # `param.grad` instead of cloning each one (~300 extra copy kernels per step otherwise)
+        for v in pvars:
+            v.grad = None
+        ctx.tape = ctx.pvars = ctx.out = None
         return (None, None, None, None, None) + grads
 
 
