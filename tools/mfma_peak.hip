@@ -2,6 +2,7 @@
 // (4 accumulators, no memory traffic).  Build + run: tools/bench_mfma_peak.py
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(256) k_mfma_loop(float* out, int iters, float a0, float b0) {
@@ -24,8 +25,10 @@ __global__ void __launch_bounds__(256) k_mfma_loop(float* out, int iters, float 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-int main() {
-    const int blocks = 256 * 8, iters = 20000;
+int main(int argc, char** argv) {
+    // blocks per CU: 8 -> 8 waves / SIMD (peak); 1 -> one wave per SIMD; 2 -> two (the conv kernels' occupancy)
+    const int per_cu = argc > 1 ? atoi(argv[1]) : 8;
+    const int blocks = 256 * per_cu, iters = 20000 * 8 / per_cu;
     float* out;
     hipMalloc(&out, sizeof(float) * blocks * 256);
     hipEvent_t e0, e1;
@@ -39,7 +42,7 @@ int main() {
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         double flops = (double)blocks * 4 /*waves*/ * iters * 32.0 /*mfma per iter*/ * (2.0 * 32 * 32 * 2);
-        printf("mfma_f32_32x32x2 loop: %.3f ms  %.1f TFLOP/s\n", ms, flops / ms / 1e9);
+        printf("mfma_f32_32x32x2 loop, %d waves/SIMD: %.3f ms  %.1f TFLOP/s\n", per_cu, ms, flops / ms / 1e9);
     }
     return 0;
 }
