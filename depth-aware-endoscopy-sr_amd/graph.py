@@ -305,6 +305,9 @@ def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, 
     return out
 
 
+FORCE_GENERAL_SEAN = False
+
+
 class MaskPack:
     """The depth masks as the reference delivers them ([B,K,H,W] float planes) plus their compressed form
     (one region byte per pixel and a device-side "not one-hot" flag, dasr_mask_compress)."""
@@ -312,6 +315,9 @@ class MaskPack:
 
     def __init__(self, planes, region=None):
         self.planes = planes
+        if FORCE_GENERAL_SEAN:               # tests: run the soft-mask kernels on one-hot masks (independent code path)
+            self.region, self.flag = None, None
+            return
         if region is not None:               # prepared on the device (prep.depth_to_masks): one-hot by construction
             self.region, self.flag = region, None
             return

@@ -97,3 +97,41 @@ def test_validation_and_folding():
 @pytest.mark.gpu
 def test_checkpoint_interop(tmp_path):
     print(pc.check_checkpoint_interop("cuda", str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_rccl_flat_allreduce_single_rank():
+    """The N > 1 code path on real device memory: RCCL (backend "nccl") initialises on this box, and the trainer's
+    flat gradient pack -> all_reduce -> / world -> unpack round-trips.  A one-rank group cannot show the sum, so the
+    trainer is told the world is 2: every gradient must come back exactly halved."""
+    import os
+    import torch.distributed as dist
+    from dasr_amd import harness
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        t = torch.arange(8, dtype=torch.float32, device="cuda")
+        dist.all_reduce(t)
+        dist.barrier()
+        assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
+        case = dict(name="rccl", scale=2, which=[0, 1], L=16, nb=4, B=1, H=8, W=12)
+        net, cfg = pc.build_net(case, "cuda")
+        tr = harness.Trainer(net, group=dist.group.WORLD)
+        lq, gt, dm, mk = [x.cuda() for x in pc.synth.seeded_batch(0, 1, 8, 12, 2)]
+        sr = net(lq, dm, mk)
+        (sr * sr).mean().backward()
+        before = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        tr.world = 2
+        tr._allreduce_grads()
+        torch.cuda.synchronize()
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, before[k] / 2), k
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_large_frame_x2_properties():
+    print(pc.check_large_frame_x2("cuda"))
