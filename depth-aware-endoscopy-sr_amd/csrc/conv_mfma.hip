@@ -360,7 +360,9 @@ struct WgradArgs {
     const float* x;      // [B,H,W,Cin]
     const float* dy;     // [B,H,W,Cout]
     float* slabs;        // [P][9][Cin][Cout]
-    float* dbias;        // [Cout], zeroed by the host, or null: column sums of dy added by the ci-group-0 workgroups
+    float* bslabs;       // [P][Cout] or null: column sums of dy (bias gradient partials) written by the ci-group-0 workgroups
+    float* zero;         // dw when the reduction will add into it with atomics (y-split), else null: zeroed here
+    size_t nzero;
     int B, H, W, Cin, Cout;
     int P, ntiles;
 };
@@ -387,8 +389,12 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_mfma(WgradArgs a) {
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const bool do_bias = a.dbias != nullptr && ci0 == 0 && tid < COG;
+    const bool do_bias = a.bslabs != nullptr && ci0 == 0 && tid < COG;
     float bsum = 0.f;
+    if (a.zero) {                                // spares a memset launch: dw is only touched by the reduce kernel after us
+        const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
+        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
+    }
 
     for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
@@ -482,7 +488,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_mfma(WgradArgs a) {
             mmak(bv1, av1);
         }
     }
-    if (do_bias) atomicAdd(&a.dbias[co0 + tid], bsum);
+    if (do_bias) a.bslabs[(size_t)blockIdx.y * a.Cout + co0 + tid] = bsum;
     float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
@@ -499,7 +505,17 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_mfma(WgradArgs a) {
 // dw = sum of P slabs.  float4 per thread, the slab range split over blockIdx.y (partial sums meet in dw through
 // float atomics when gridDim.y > 1; dw is zeroed first).
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, size_t n4,
-                                                      int P, int per_y) {
+                                                      int P, int per_y, int gx, const float* __restrict__ bslabs,
+                                                      float* __restrict__ dbias, int Cout) {
+    if ((int)blockIdx.x >= gx) {                 // tail blocks: bias gradient = fixed-order sum of the P partials
+        const int c = (blockIdx.x - gx) * 256 + threadIdx.x;
+        if (blockIdx.y == 0 && c < Cout) {
+            float acc = 0.f;
+            for (int p = 0; p < P; ++p) acc += bslabs[(size_t)p * Cout + c];
+            dbias[c] = acc;
+        }
+        return;
+    }
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const int p0 = blockIdx.y * per_y;
@@ -525,18 +541,27 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
     }
 }
 
-int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* stream) {
-    // n is a multiple of 4 for every supported shape (Cout % 32 == 0)
-    size_t n4 = n / 4;
+static int wgrad_reduce_ysplit(size_t n4, int P) {
     unsigned gx = dasr_cdiv(n4, 256);
     int ysplit = 1;
     while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
+    return ysplit;
+}
+// dw_is_zero: the producer already cleared dw (k_conv3x3_wgrad_mfma does when asked); bslabs/dbias: optional bias tail
+int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* stream, bool dw_is_zero,
+                        const float* bslabs, float* dbias, int Cout) {
+    // n is a multiple of 4 for every supported shape (Cout % 32 == 0)
+    size_t n4 = n / 4;
+    unsigned gx = dasr_cdiv(n4, 256);
+    const int ysplit = wgrad_reduce_ysplit(n4, P);
     int per_y = (P + ysplit - 1) / ysplit;
-    if (ysplit > 1) {
+    if (ysplit > 1 && !dw_is_zero) {
         hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * n, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    DASR_LAUNCH(k_wgrad_reduce, dim3(gx, ysplit), dim3(256), 0, stream, slabs, dw, n4, P, per_y);
+    const unsigned tail = dbias ? dasr_cdiv((size_t)Cout, 256) : 0;
+    DASR_LAUNCH(k_wgrad_reduce, dim3(gx + tail, ysplit), dim3(256), 0, stream, slabs, dw, n4, P, per_y, (int)gx, bslabs,
+                dbias, Cout);
     DASR_RETURN_LAUNCH_STATUS();
 }
 
@@ -557,17 +582,17 @@ static void wgrad_plan(const ConvGeom& g, int& MT, int& NTW, int& groups, int& n
 size_t conv_mfma_wgrad_workspace(const ConvGeom& g) {
     int MT, NTW, groups, ntiles, P;
     wgrad_plan(g, MT, NTW, groups, ntiles, P);
-    return sizeof(float) * (size_t)P * 9 * g.Cin * g.Cout;
+    return sizeof(float) * ((size_t)P * 9 * g.Cin * g.Cout + (size_t)P * g.Cout);   // weight slabs + bias partials
 }
 int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
                     void* stream) {
     int MT, NTW, groups, ntiles, P;
     wgrad_plan(g, MT, NTW, groups, ntiles, P);
-    if (dbias) {
-        hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * g.Cout, (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-    }
-    WgradArgs a{x, dconv, (float*)workspace, dbias, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
+    const size_t nW = (size_t)9 * g.Cin * g.Cout;
+    float* slabs = (float*)workspace;
+    float* bslabs = dbias ? slabs + (size_t)P * nW : nullptr;
+    const bool ysplit = wgrad_reduce_ysplit(nW / 4, P) > 1;
+    WgradArgs a{x, dconv, slabs, bslabs, ysplit ? dw : nullptr, ysplit ? nW : 0, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
     const int th = wg_th(MT, NTW);
     size_t lds = sizeof(float) * (size_t)((th + 2) * (WG_TW + 2) * 32 * MT + th * WG_TW * 32 * NTW);
     dim3 grid(groups, P);
@@ -580,5 +605,5 @@ int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float
     } else {
         DASR_LAUNCH((k_conv3x3_wgrad_mfma<1, 1>), grid, dim3(256), lds, stream, a);
     }
-    return wgrad_reduce_launch((const float*)workspace, dw, (size_t)9 * g.Cin * g.Cout, P, stream);
+    return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit, bslabs, dbias, g.Cout);
 }

@@ -806,6 +806,17 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
     DASR_RETURN_LAUNCH_STATUS();
 }
 
+__global__ void __launch_bounds__(256) k_sean_bwd_zero(float* __restrict__ S, int nS, float* __restrict__ dbg,
+                                                       float* __restrict__ dbb, int C, float* __restrict__ dag,
+                                                       float* __restrict__ dab) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nS) S[i] = 0.f;
+    else if (i < nS + C) dbg[i - nS] = 0.f;
+    else if (i < nS + 2 * C) dbb[i - nS - C] = 0.f;
+    else if (i == nS + 2 * C) dag[0] = 0.f;
+    else if (i == nS + 2 * C + 1) dab[0] = 0.f;
+}
+
 extern "C" size_t dasr_sean_bwd_workspace(int B, int H, int W, int C, int K) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
     size_t S = 2 * (size_t)B * C;
@@ -832,15 +843,17 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
     hipStream_t st = (hipStream_t)stream;
     float* S = (float*)workspace;
     float* slabs = S + 2 * (size_t)B * C;
-    hipError_t e;
-    if ((e = hipMemsetAsync(S, 0, sizeof(float) * 2 * (size_t)B * C, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(dD, 0, sizeof(float) * (size_t)B * 18 * K * C, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(dbias_g, 0, sizeof(float) * (size_t)C, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(dbias_b, 0, sizeof(float) * (size_t)C, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(dalpha_g, 0, sizeof(float), st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(dalpha_b, 0, sizeof(float), st)) != hipSuccess) return (int)e;
     const bool fast = region != nullptr && (C % 4) == 0;
     const bool fast_only = fast && onehot_flag == nullptr;
+    // the accumulators the kernels add into with atomics: one launch instead of five memsets; dD is only accumulated
+    // into by the general kernel (the one-hot path overwrites all of it in k_sean_dD_reduce)
+    (void)st;
+    DASR_LAUNCH(k_sean_bwd_zero, dim3(dasr_cdiv((size_t)2 * B * C + 2 * C + 2, 256)), dim3(256), 0, stream, S, 2 * B * C,
+                dbias_g, dbias_b, C, dalpha_g, dalpha_b);
+    if (!fast_only) {
+        hipError_t e = hipMemsetAsync(dD, 0, sizeof(float) * (size_t)B * 18 * K * C, st);
+        if (e != hipSuccess) return (int)e;
+    }
     if (fast) {
         int nblk = sean_bwd_blocks_per_sample(B, H, W);
         int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SB_TH - 1) / SB_TH);
