@@ -277,6 +277,38 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const float* __restrict__ t,
 }
 
 
+// Same as the float4 branch above for C4 = C/4 dividing 256: blockIdx.y = sample, a thread keeps ONE channel quad
+// and walks the pixels, so the per-(b,c) factors (two rsqrt-style scales and their derivative: 16 sqrt/div per float4
+// in the kernel above, plus two 64-bit divisions for the index) are computed once per thread.
+__global__ void __launch_bounds__(256) k_sean_bwd_b_rows(const float* __restrict__ t, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, const float* __restrict__ S,
+                                                         float* __restrict__ dt, int HW, int C, float eps) {
+    const int C4 = C >> 2, q = threadIdx.x % C4, pl = threadIdx.x / C4, npl = 256 / C4;
+    const int b = blockIdx.y, c = 4 * q;
+    const float invN = 1.0f / (float)HW;
+    const size_t bc = (size_t)b * C + c;
+    const float4 mu = *(const float4*)(mean + bc), vr = *(const float4*)(var + bc);
+    const float4 s01 = *(const float4*)(S + 2 * bc), s23 = *(const float4*)(S + 2 * bc + 4);
+    const float4 A = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
+                                 dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
+    const float4 Bm = make_float4(s01.x * invN, s01.z * invN, s23.x * invN, s23.z * invN);
+    const float4 D2 = make_float4(dasr_double_in_dscale(vr.x, eps) * 2.f * invN, dasr_double_in_dscale(vr.y, eps) * 2.f * invN,
+                                  dasr_double_in_dscale(vr.z, eps) * 2.f * invN, dasr_double_in_dscale(vr.w, eps) * 2.f * invN);
+    const float4 S1 = make_float4(s01.y, s01.w, s23.y, s23.w);
+    const float* tb = t + (size_t)b * HW * C + c;
+    float* db = dt + (size_t)b * HW * C + c;
+    for (int p = blockIdx.x * npl + pl; p < HW; p += gridDim.x * npl) {
+        const float4 tv = *(const float4*)(tb + (size_t)p * C);
+        float4 dv = *(const float4*)(db + (size_t)p * C);
+        // same expression order as the general kernel: s*(dv - S0/N) + (ds*2/N)*(t - mu)*S1
+        dv.x = A.x * (dv.x - Bm.x) + D2.x * (tv.x - mu.x) * S1.x;
+        dv.y = A.y * (dv.y - Bm.y) + D2.y * (tv.y - mu.y) * S1.y;
+        dv.z = A.z * (dv.z - Bm.z) + D2.z * (tv.z - mu.z) * S1.z;
+        dv.w = A.w * (dv.w - Bm.w) + D2.w * (tv.w - mu.w) * S1.w;
+        *(float4*)(db + (size_t)p * C) = dv;
+    }
+}
+
 // =====================================================================================================
 // One-hot fast path.
 //
@@ -874,7 +906,14 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
                     dres, S, relu, eps, fast ? onehot_flag : (const int*)nullptr);
     }
     size_t n = (size_t)B * H * W * C;
-    DASR_LAUNCH(k_sean_bwd_b, dim3(dasr_ew_grid((C & 3) == 0 ? n / 4 : n)), dim3(256), 0, stream, t, mean, var, S, dt,
-                H * W, C, n, eps);
+    if ((C & 3) == 0 && (256 % (C / 4)) == 0 && B <= 65535) {
+        const int npl = 256 / (C / 4);
+        unsigned gx = dasr_cdiv((size_t)H * W, npl * 8);     // eight pixels per thread
+        if (gx < 1) gx = 1;
+        DASR_LAUNCH(k_sean_bwd_b_rows, dim3(gx, B), dim3(256), 0, stream, t, mean, var, S, dt, H * W, C, eps);
+    } else {
+        DASR_LAUNCH(k_sean_bwd_b, dim3(dasr_ew_grid((C & 3) == 0 ? n / 4 : n)), dim3(256), 0, stream, t, mean, var, S,
+                    dt, H * W, C, n, eps);
+    }
     DASR_RETURN_LAUNCH_STATUS();
 }

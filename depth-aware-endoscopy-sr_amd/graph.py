@@ -27,6 +27,8 @@ FUSE_DGRAD_ACT = False
 SIDE_STREAM = True
 # Weight / bias gradients are off the critical path of the backward (nothing but the optimiser waits for them): they
 # run on a third stream and fill whatever the data-gradient chain leaves idle.
+import os as _os
+TAIL_WGRAD_SIDE = False  # weight gradients of the HR tail on the (then idle) depth-branch stream; see conv(side_wgrad=)
 WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
 
@@ -34,7 +36,8 @@ _SIDE = {}
 def _side_stream(device, which="branch"):
     key = (str(device), which)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
+        # high priority: the depth branch is the longer of the two chains in both directions (measured +0.8 %)
+        _SIDE[key] = torch.cuda.Stream(device=device, priority=-1)
     return _SIDE[key]
 
 
@@ -137,7 +140,8 @@ def bias_pair(tape, ba, bb):
     return out
 
 
-def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.ACT_NONE, ps_r=1, residual=None):
+def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.ACT_NONE, ps_r=1, residual=None,
+         side_wgrad=False):
     y = ops.conv2d_fwd(x.data, w.data, bias.data if bias is not None else None,
                        residual.data if residual is not None else None, stride, pad, transposed, act, ps_r)
     needs = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad) or \
@@ -177,6 +181,8 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             dconv = dy
         if w.requires_grad or (bias is not None and bias.requires_grad):
             ws = _side_stream(dconv.device, "wgrad") if (WGRAD_STREAM and dconv.is_cuda) else None
+            if ws is None and side_wgrad and TAIL_WGRAD_SIDE and SIDE_STREAM and dconv.is_cuda:
+                ws = _side_stream(dconv.device)       # the depth-branch stream: idle while the HR tail runs backward
             if ws is None:
                 dw, db = ops.conv2d_wgrad(x.data, dconv, wshape, stride, pad, transposed, want_bias=bias is not None)
             else:
@@ -407,15 +413,16 @@ def depth_block(tape, P, name, x, depth_map, mask, st, consts, gb2_pair=None):
 
 def classic_block(tape, P, name, x):
     """Classic_Residual_Block.forward (sftmd_arch.py:147-151)."""
-    h = conv(tape, x, _wn(tape, P, name + ".block.0"), P[name + ".block.0.bias"], act=ops.ACT_RELU)
-    return conv(tape, h, _wn(tape, P, name + ".block.2"), P[name + ".block.2.bias"], act=ops.ACT_RELU, residual=x)
+    h = conv(tape, x, _wn(tape, P, name + ".block.0"), P[name + ".block.0.bias"], act=ops.ACT_RELU, side_wgrad=True)
+    return conv(tape, h, _wn(tape, P, name + ".block.2"), P[name + ".block.2.bias"], act=ops.ACT_RELU, residual=x,
+                side_wgrad=True)
 
 
 def upscale(tape, P, name, x, r, second):
     """upscale1/2/3 (sftmd_arch.py:891-908): conv -> PixelShuffle(r) -> LeakyReLU [-> conv -> LeakyReLU]."""
-    x = conv(tape, x, _wn(tape, P, name + ".0"), P[name + ".0.bias"], act=ops.ACT_LRELU, ps_r=r)
+    x = conv(tape, x, _wn(tape, P, name + ".0"), P[name + ".0.bias"], act=ops.ACT_LRELU, ps_r=r, side_wgrad=True)
     if second:
-        x = conv(tape, x, _wn(tape, P, name + ".3"), P[name + ".3.bias"], act=ops.ACT_LRELU)
+        x = conv(tape, x, _wn(tape, P, name + ".3"), P[name + ".3.bias"], act=ops.ACT_LRELU, side_wgrad=True)
     return x
 
 
@@ -491,7 +498,7 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=No
         fea = upscale(tape, P, "upscale2", fea, 2, True)
     fea = run_block(nb - 1, fea)
     fea = upscale(tape, P, "upscale3", fea, 3 if scale == 3 else 2, False)
-    y = conv(tape, fea, pack(tape, P["conv_output.weight"]), P["conv_output.bias"], pad=4)     # :948
+    y = conv(tape, fea, pack(tape, P["conv_output.weight"]), P["conv_output.bias"], pad=4, side_wgrad=True)     # :948
     lo, hi = cfg["out_min"], cfg["out_max"]
     out = Var(ops.clamp_to_nchw(y.data, lo, hi), True)                                          # :950
 
