@@ -148,6 +148,10 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
     prefetch(0);
     CM_T_MARK(0);
     for (int c0 = 0; c0 < a.Cin; c0 += CM_CK) {
+#ifdef DASR_CONV_NOSTAGE       // experiment only (tools/conv_phase_timing.py): the MFMA loop on whatever is in LDS
+        if (c0 == 0)
+#endif
+        {
         __syncthreads();                       // every wave is done reading the previous chunk
         CM_T_MARK(1);
         commit();
@@ -156,6 +160,7 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
         CM_T_MARK(3);
         if (c0 + CM_CK < a.Cin) prefetch(c0 + CM_CK);
         CM_T_MARK(4);
+        }
         // ---- 9 taps x 16 channels = 18 fragment steps of 4 K=2 MFMAs per accumulator.  The LDS reads of step j+1
         // are issued before the MFMAs of step j (two statically named fragment sets), so the matrix pipe never
         // waits for a ds_read at the start of a step.

@@ -15,7 +15,7 @@ out = os.path.join(root, "gpurun_out", "libdasr_timing.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 srcs = sorted(glob.glob(os.path.join(root, "depth-aware-endoscopy-sr_amd", "csrc", "*.hip")))
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-ffp-contract=on", "-DDASR_CONV_TIMING", "-o", out] + srcs)
+                       "-ffp-contract=on"] + (os.environ.get("DASR_EXTRA_DEFS", "-DDASR_CONV_TIMING").split()) + ["-o", out] + srcs)
 lib = ctypes.CDLL(out)
 args = [int(v) for v in sys.argv[1:]]
 Cin, Cout = (args + [128, 128])[:2] if len(args) >= 2 else (128, 128)
@@ -39,13 +39,17 @@ def run():
 buf = (ctypes.c_ulonglong * 8)()
 run()
 torch.cuda.synchronize()
-lib.dasr_debug_conv_phase_read(buf, 1)
+if hasattr(lib, "dasr_debug_conv_phase_read"):
+    lib.dasr_debug_conv_phase_read(buf, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
     run()
 e1.record()
 torch.cuda.synchronize()
+print("conv3x3 %dx%d %d->%d B=%d: %.1f us / launch  [%s]" % (H, W, Cin, Cout, B, e0.elapsed_time(e1) * 100, os.environ.get("DASR_EXTRA_DEFS", "-DDASR_CONV_TIMING")))
+if not hasattr(lib, "dasr_debug_conv_phase_read"):
+    sys.exit(0)
 lib.dasr_debug_conv_phase_read(buf, 1)
 names = ["prologue prefetch", "barrier 1 (chunk done)", "commit (vmcnt wait + ds_write)", "barrier 2", "issue next prefetch",
          "MFMA loop", "epilogue", "-"]
