@@ -187,7 +187,10 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
         };
         float4 A0[2], B0[NT], A1[2], B1[NT];
         ldfrag(0, A0, B0);
-#pragma unroll 1
+        // 16-row tiles: fully unrolled, every LDS address becomes "base register + immediate" (tap offsets are
+        // compile-time), no integer multiplies between the MFMAs (128->128: 775 -> 735 us).  8-row tiles and NT = 1 keep the rolled
+        // loop: two independent workgroups per CU then run different parts of a 5 KB loop body and lose (242 -> 254 us).
+#pragma unroll(CM_TH == 16 && NT == 2 ? 9 : 1)
         for (int j = 0; j < 18; j += 2) {
             ldfrag(j + 1, A1, B1);
             mma(A0, B0);
@@ -485,7 +488,10 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_mfma(WgradArgs a) {
         float bv0, bv1, av0[NACC], av1[NACC];
         constexpr int NS = WG_TH * WG_TW / 2;
         ldk(0, bv0, av0);
-#pragma unroll 1
+        // fully unrolled for the square blocks: LDS addresses become immediates, no index math between the MFMAs
+        // (measured: 64x64 block 864 -> 776 us at 128->128, 32x32 block 1330 -> 1155 us at 512x640; the 64x32 / 32x64
+        // blocks lose 25-60 % when unrolled and keep the rolled loop)
+#pragma unroll(MT == NTW ? NS / 2 : 1)
         for (int s = 0; s < NS; s += 2) {
             ldk(s + 1, bv1, av1);
             mmak(bv0, av0);
@@ -513,11 +519,29 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
                                                       int P, int per_y, int gx, const float* __restrict__ bslabs,
                                                       float* __restrict__ dbias, int Cout) {
     if ((int)blockIdx.x >= gx) {                 // tail blocks: bias gradient = fixed-order sum of the P partials
-        const int c = (blockIdx.x - gx) * 256 + threadIdx.x;
-        if (blockIdx.y == 0 && c < Cout) {
-            float acc = 0.f;
-            for (int p = 0; p < P; ++p) acc += bslabs[(size_t)p * Cout + c];
-            dbias[c] = acc;
+        // 32 channels per block, 8 slab parts per channel, eight loads in flight per thread (a one-load-per-trip
+        // loop over P = 512 partials is a 512-deep latency chain)
+        __shared__ float bpart[8][32];
+        const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
+        const int c = (blockIdx.x - gx) * 32 + cl;
+        if (blockIdx.y != 0) return;
+        float acc = 0.f;
+        if (c < Cout) {
+            for (int p0 = q; p0 < P; p0 += 64) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p0 + 8 * u < P ? bslabs[(size_t)(p0 + 8 * u) * Cout + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+        }
+        bpart[q][cl] = acc;
+        __syncthreads();
+        if (q == 0 && c < Cout) {
+            float r = bpart[0][cl];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) r += bpart[t][cl];
+            dbias[c] = r;
         }
         return;
     }
@@ -564,7 +588,7 @@ int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* st
         hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * n, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    const unsigned tail = dbias ? dasr_cdiv((size_t)Cout, 256) : 0;
+    const unsigned tail = dbias ? dasr_cdiv((size_t)Cout, 32) : 0;
     DASR_LAUNCH(k_wgrad_reduce, dim3(gx + tail, ysplit), dim3(256), 0, stream, slabs, dw, n4, P, per_y, (int)gx, bslabs,
                 dbias, Cout);
     DASR_RETURN_LAUNCH_STATUS();
