@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_conv9x9_fwd_mfma(Conv9Args a) {
             sW[((idx / (C9_CK * 32)) * 32 + (idx / C9_CK) % 32) * C9_CKP + idx % C9_CK] = vw[u];
         }
         __syncthreads();
-#pragma unroll 3
+#pragma unroll
         for (int kh = 0; kh < 9; ++kh) {
 #pragma unroll
             for (int q = 0; q < C9_CK / 8; ++q) {
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll 1
     for (int kh = 0; kh < 9; ++kh) {
-#pragma unroll 2
+#pragma unroll
         for (int s = 0; s < 14; ++s) {
             const float bv = sW[(kh * 28 + 2 * s + lh) * 32 + li];
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) k_conv9x9_wgrad_mfma(Conv9Args a) {
             }
         }
         __syncthreads();
-#pragma unroll 2
+#pragma unroll 8
         for (int s = 0; s < 2 * C9_TQ / 2; ++s) {       // this wave's 2 rows x 64 columns, two pixels per step
             const int r = 2 * wv + s / (C9_TQ / 2), qx = 2 * (s % (C9_TQ / 2)) + lh;
             const float av = sX[(r * C9_TQ + qx) * 32 + li];

@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
         // ---- phase 2: one-hot(region) x G on the matrix cores; 4 pixels per MFMA step
         {
             const int i16 = lane & 15, k4 = lane >> 4;
-#pragma unroll 2
+#pragma unroll 8
             for (int s = 0; s < SB_TH * SF_TW / 4; ++s) {
                 const int q = 4 * s + k4;                     // tile-local pixel of this lane's K slot
                 const int ly = q / SF_TW, lx = q % SF_TW;
