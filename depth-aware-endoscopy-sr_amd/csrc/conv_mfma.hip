@@ -188,9 +188,9 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
         float4 A0[2], B0[NT], A1[2], B1[NT];
         ldfrag(0, A0, B0);
         // 16-row tiles: fully unrolled, every LDS address becomes "base register + immediate" (tap offsets are
-        // compile-time), no integer multiplies between the MFMAs (128->128: 775 -> 735 us).  8-row tiles and NT = 1 keep the rolled
-        // loop: two independent workgroups per CU then run different parts of a 5 KB loop body and lose (242 -> 254 us).
-#pragma unroll(CM_TH == 16 && NT == 2 ? 9 : 1)
+        // compile-time), no integer multiplies between the MFMAs (128->128: 775 -> 735 us).  8-row tiles and NT = 1 lose when
+        // fully unrolled (242 -> 254 us) but gain from unrolling one kernel row (3 taps: dx immediate, dy by increment).
+#pragma unroll(CM_TH == 16 && NT == 2 ? 9 : 3)
         for (int j = 0; j < 18; j += 2) {
             ldfrag(j + 1, A1, B1);
             mma(A0, B0);
