@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_mfma(WgradArgs a) {
         constexpr int NX = (WG_TH + 2) * (WG_TW + 2) * (CIG / 4), NXI = (NX + 255) / 256;
         constexpr int ND = WG_TH * WG_TW * (COG / 4), NDI = (ND + 255) / 256;
         // the 64x64 block already holds 144 accumulator registers: its x loads go in two batches (256-VGPR budget)
-        constexpr int XA = MT * NTW == 4 ? 4 : NXI;
+        constexpr int XA = MT * NTW == 4 ? (NDI >= 8 ? 1 : 8 - NDI) : NXI;
         float4 vx[XA > NXI - XA ? XA : NXI - XA], vd[NDI];
         auto ldx = [&](int u) {
             const int idx = tid + 256 * u;
@@ -601,6 +601,9 @@ bool conv_mfma_wgrad_supported(const ConvGeom& g) {
 static void wgrad_plan(const ConvGeom& g, int& MT, int& NTW, int& groups, int& ntiles, int& P) {
     MT = (g.Cin % 64) == 0 ? 2 : 1;
     NTW = (g.Cout % 64) == 0 ? 2 : 1;
+    // 32 input channels x a multiple of 128 output channels (the upscale convs): a 32x128 block gives every wave all
+    // nine taps (no zero-padded tap slots; the 32x64 block wastes one slot in ten)
+    if (MT == 1 && (g.Cout % 128) == 0) NTW = 4;
     groups = (g.Cin / (32 * MT)) * (g.Cout / (32 * NTW));
     const int th = wg_th(MT, NTW);
     ntiles = g.B * ((g.H + th - 1) / th) * ((g.W + WG_TW - 1) / WG_TW);
@@ -629,6 +632,8 @@ int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float
         DASR_LAUNCH((k_conv3x3_wgrad_mfma<2, 2>), grid, dim3(256), lds, stream, a);
     } else if (MT == 2 && NTW == 1) {
         DASR_LAUNCH((k_conv3x3_wgrad_mfma<2, 1>), grid, dim3(256), lds, stream, a);
+    } else if (MT == 1 && NTW == 4) {
+        DASR_LAUNCH((k_conv3x3_wgrad_mfma<1, 4>), grid, dim3(256), lds, stream, a);
     } else if (MT == 1 && NTW == 2) {
         DASR_LAUNCH((k_conv3x3_wgrad_mfma<1, 2>), grid, dim3(256), lds, stream, a);
     } else {
