@@ -64,10 +64,10 @@ def block_inputs():
 
 # ---- whole net ------------------------------------------------------------------------------
 DEPTHNET_CASES = [
-    dict(name="x8_nb4", scale=8, which=[0, 1], L=32, nb=4, B=2, H=8, W=12),
+    dict(name="x8_nb4", scale=8, which=[0, 1], L=32, nb=4, B=2, H=6, W=8),
     dict(name="x4_nb4", scale=4, which=[0, 1], L=32, nb=4, B=1, H=12, W=16),
     dict(name="x3_nb4", scale=3, which=[0, 1], L=32, nb=4, B=1, H=9, W=12),
-    dict(name="x2_nb4", scale=2, which=[0, 1, 2, 3], L=32, nb=4, B=1, H=12, W=16),
+    dict(name="x2_nb4", scale=2, which=[0, 1, 2, 3], L=32, nb=4, B=1, H=8, W=12),
     dict(name="x8_nb5_odd", scale=8, which=[0, 1, 2], L=16, nb=5, B=1, H=7, W=9),
 ]
 

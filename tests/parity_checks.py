@@ -99,7 +99,9 @@ def check_depthnet_case(case, device, lin_tol=2e-3, loss_tol=0.1, lin64_tol=1e-4
     err64 = float(np.abs(sr0.cpu().numpy().astype(np.float64) - g["sr64"]).max())
     assert err64 <= 1e-4, ("forward vs fp64 reference", case["name"], err64)
     assert l64 <= lin_tol, ("linear-functional grads vs fp64 reference", case["name"], l64, worst64)
-    # ... and tightly with at least one of the two reference runs (a flip can land on either side)
+    # ... and more tightly with at least one of the two reference runs.  Smooth cases sit at 1e-6; a single ReLU / clamp
+    # decision flipping in THIS implementation's rounding (neither reference run flips) moves the whole-net gradient
+    # by up to ~1e-3 (x8_nb4 at 6x8: 5.7e-4), hence 2e-3 rather than 1e-4
     assert min(l2, l64) <= lin64_tol, ("linear-functional grads: neither reference run matched", case["name"], l2, l64)
     # (b) the harness loss (L1 + dynamic): sign() of the L1 term makes this one only loosely comparable
     net.zero_grad(set_to_none=True)

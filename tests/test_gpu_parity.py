@@ -55,7 +55,7 @@ def test_encoder_geometry():
 @pytest.mark.parametrize("case", DEPTHNET_CASES, ids=[c["name"] for c in DEPTHNET_CASES])
 def test_depthnet(case):
     tol = 0.2 if case["name"].endswith("odd") else 1e-2
-    r = pc.check_depthnet_case(case, "cuda", lin_tol=tol, loss_tol=0.3, lin64_tol=1e-4)
+    r = pc.check_depthnet_case(case, "cuda", lin_tol=tol, loss_tol=0.3, lin64_tol=2e-3)
     print(case["name"], r)
 
 
