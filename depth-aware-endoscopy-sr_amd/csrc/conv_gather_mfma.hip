@@ -84,22 +84,32 @@ __global__ void __launch_bounds__(256) k_conv_gather_mfma(GatherArgs a) {
             if (!__any(ok)) continue;                       // dead tap for this whole M-tile
             const float* src = ok ? a.in + (((size_t)b * a.Hi + iy) * a.Wi + ix) * a.Kd : a.in;
             const int tap = kh * a.KW + kw;
-            for (int c0 = 0; c0 < a.Kd; c0 += 8) {
-                float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) A = *(const float4*)(src + c0 + 4 * lh);
-                float4 Bf[NT];
+            // four 8-channel steps per trip: their 4 * (1 + NT) operand loads are issued before the first MFMA (one step
+            // per trip exposed an L2 round trip per 4*NT MFMAs)
+            for (int c0 = 0; c0 < a.Kd; c0 += 32) {
+                float4 A[4], Bf[4][NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int nn = n0 + 32 * n + li;
-                    // [tap][n][k] with k contiguous: the transposed half for the forward, the HWIO half for dgrad
-                    Bf[n] = *(const float4*)(a.w + ((size_t)tap * a.Nd + nn) * a.Kd + c0 + 4 * lh);
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = c0 + 8 * u < a.Kd ? c0 + 8 * u : c0;      // clamped: the extra steps are skipped below
+                    A[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) A[u] = *(const float4*)(src + cc + 4 * lh);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int nn = n0 + 32 * n + li;
+                        // [tap][n][k] with k contiguous: the transposed half for the forward, the HWIO half for dgrad
+                        Bf[u][n] = *(const float4*)(a.w + ((size_t)tap * a.Nd + nn) * a.Kd + cc + 4 * lh);
+                    }
                 }
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, Bf[n].x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, Bf[n].y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, Bf[n].z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, Bf[n].w, acc[n], 0, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+                    if (c0 + 8 * u >= a.Kd) break;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].x, Bf[u][n].x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].y, Bf[u][n].y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].z, Bf[u][n].z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].w, Bf[u][n].w, acc[n], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -151,21 +161,33 @@ __global__ void __launch_bounds__(256) k_conv_gather_wgrad_mfma(GatherWgradArgs 
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    for (size_t mb = m0; mb < m1; mb += 2) {
-        const size_t m = mb + lh;
-        float av = 0.f, b0 = 0.f, b1 = 0.f;
-        if (m < m1) {
-            const int ox = (int)(m % a.Wo), oy = (int)((m / a.Wo) % a.Ho), b = (int)(m / ((size_t)a.Wo * a.Ho));
-            int iy, ix;
-            if (gather_src(ga, oy, ox, kh, kw, iy, ix)) {
-                av = a.x[(((size_t)b * a.H + iy) * a.W + ix) * a.Cin + 32 * ct + li];
-                const float* dp = a.dy + m * a.Cout + 64 * cp + li;
-                b0 = dp[0];
-                b1 = dp[32];
+    // Eight pixel pairs per trip: all 24 operand loads are issued before the first MFMA (one load -> MFMA per trip made
+    // this loop a chain of global-memory latencies: 2.4 ms for a 3 GFLOP layer).  32-bit index arithmetic (M < 2^31).
+    constexpr int GU = 8;
+    const unsigned Wo = (unsigned)a.Wo, HoWo = (unsigned)(a.Ho * a.Wo);
+    for (size_t mb = m0; mb < m1; mb += 2 * GU) {
+        float av[GU], b0[GU], b1[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const size_t m = mb + 2 * u + lh;
+            av[u] = b0[u] = b1[u] = 0.f;
+            if (m < m1) {
+                const unsigned mm = (unsigned)m, b = mm / HoWo, rem = mm - b * HoWo;
+                const int oy = (int)(rem / Wo), ox = (int)(rem - (unsigned)oy * Wo);
+                int iy, ix;
+                if (gather_src(ga, oy, ox, kh, kw, iy, ix)) {
+                    av[u] = a.x[(((size_t)b * a.H + iy) * a.W + ix) * a.Cin + 32 * ct + li];
+                    const float* dp = a.dy + m * a.Cout + 64 * cp + li;
+                    b0[u] = dp[0];
+                    b1[u] = dp[32];
+                }
             }
         }
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b0[u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b1[u], acc[1], 0, 0, 0);
+        }
     }
     float* slab = a.slabs + (size_t)blockIdx.y * a.KH * a.KW * a.Cin * a.Cout;
 #pragma unroll
