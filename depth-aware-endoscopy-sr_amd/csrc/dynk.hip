@@ -37,10 +37,18 @@ __global__ void __launch_bounds__(256) k_dynk_D_mfma(const float* __restrict__ s
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int l = lh; l < L; l += 2) {
-        const float av = mv ? ap[l] : 0.f;
-        const float bv = nv ? bp[(size_t)l * 9] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    // sixteen K steps per trip: 32 operand loads in flight before the first MFMA (one load pair per MFMA was a chain of
+    // L/2 = 128 L2 round trips: 77 us for 6 MFLOP)
+    for (int l0 = lh; l0 < L; l0 += 32) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int l = l0 + 2 * u;
+            av[u] = (mv && l < L) ? ap[l] : 0.f;
+            bv[u] = (nv && l < L) ? bp[(size_t)l * 9] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
     }
     if (!nv) return;
 #pragma unroll
@@ -83,14 +91,20 @@ __global__ void __launch_bounds__(256) k_dynk_dW_mfma(const float* __restrict__ 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int kk = lh; kk < KK + (KK & 1); kk += 2) {
-        float av = 0.f, bv = 0.f;
-        if (kk < KK) {
-            const int b = kk / K, k = kk % K;
-            if (mv) av = dD[(((size_t)b * 18 + st) * K + k) * C + c];
-            if (nv) bv = stp[(size_t)kk * L + n];
+    for (int kk0 = lh; kk0 < KK; kk0 += 32) {          // sixteen K steps per trip, loads first (see k_dynk_D_mfma)
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int kk = kk0 + 2 * u;
+            av[u] = bv[u] = 0.f;
+            if (kk < KK) {
+                const int b = kk / K, k = kk % K;
+                if (mv) av[u] = dD[(((size_t)b * 18 + st) * K + k) * C + c];
+                if (nv) bv[u] = stp[(size_t)kk * L + n];
+            }
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
     }
     if (!nv) return;
 #pragma unroll
@@ -112,7 +126,18 @@ __global__ void k_dynk_dstp(const float* __restrict__ dD, const float* __restric
         size_t b = i / ((size_t)L * K);
         const float* dp = dD + ((b * 18 + st) * K + k) * C;
         float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc = fmaf(dp[c], Wp[((size_t)c * L + l) * 9 + tap], acc);
+        for (int c0 = 0; c0 < C; c0 += 8) {            // eight (dD, W) pairs in flight; same summation order
+            float dv[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u < C ? c0 + u : C - 1;
+                dv[u] = dp[c];
+                wv[u] = Wp[((size_t)c * L + l) * 9 + tap];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < C) acc = fmaf(dv[u], wv[u], acc);
+        }
         atomicAdd(&dstp[i], acc);
     }
 }

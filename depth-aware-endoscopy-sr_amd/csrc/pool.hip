@@ -44,7 +44,18 @@ __global__ void k_pool_fwd(const float* __restrict__ feat, const float* __restri
         const float* m = maskr + (b * K + k) * hw;
         const float* f = feat + b * (size_t)hw * L + l;
         float acc = 0.f;
-        for (int p = 0; p < hw; ++p) acc = fmaf(m[p], f[(size_t)p * L], acc);
+        for (int p0 = 0; p0 < hw; p0 += 16) {        // sixteen (mask, feature) pairs in flight; same summation order
+            float mv[16], fv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int p = p0 + u < hw ? p0 + u : hw - 1;
+                mv[u] = m[p];
+                fv[u] = f[(size_t)p * L];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (p0 + u < hw) acc = fmaf(mv[u], fv[u], acc);
+        }
         out[i] = acc / (area[b * K + k] + 1e-10f);
     }
 }
