@@ -78,7 +78,9 @@ extern "C" int dasr_dynk_fwd(const float* st, const float* A_w, const float* A_b
 // dW_s[c,l,tap] = sum_{(b,k)} dD[b,st,k,c] * stp[b,k,l]      M = (st,c), N = l, K = (b,k)
 __global__ void __launch_bounds__(256) k_dynk_dW_mfma(const float* __restrict__ dD, const float* __restrict__ stp,
                                                       float* __restrict__ dWg, float* __restrict__ dWb, int B, int K,
-                                                      int L, int C) {
+                                                      int L, int C, float* __restrict__ zero, size_t nzero) {
+    // clears the accumulator the NEXT kernel (k_dynk_dstp) adds into: spares a memset dispatch per SEAN
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nzero; i += (size_t)gridDim.x * 256) zero[i] = 0.f;
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const int M = 18 * C, N = L, KK = B * K;
     const int tiles_n = (N + 31) / 32;
@@ -185,10 +187,8 @@ extern "C" int dasr_dynk_bwd(const float* dD, const float* st, const float* stp,
     (void)nW;
     {
         int tiles = ((18 * C + 31) / 32) * ((L + 31) / 32);
-        DASR_LAUNCH(k_dynk_dW_mfma, dim3((tiles + 3) / 4), dim3(256), 0, stream, dD, stp, dWg, dWb, B, K, L, C);
+        DASR_LAUNCH(k_dynk_dW_mfma, dim3((tiles + 3) / 4), dim3(256), 0, stream, dD, stp, dWg, dWb, B, K, L, C, dstp, nS);
     }
-    hipError_t e = hipMemsetAsync(dstp, 0, sizeof(float) * nS, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
     DASR_LAUNCH(k_dynk_dstp, dim3(dasr_ew_grid(nS), 18), dim3(256), 0, stream, dD, Wg, Wb, dstp, K, L, C, nS);
     DASR_LAUNCH(k_dynk_dA, dim3(K * K + K), dim3(256), 0, stream, dstp, st, dA_w, dA_b, B, K, L);
     DASR_LAUNCH(k_dynk_dst, dim3(dasr_ew_grid(nS)), dim3(256), 0, stream, dstp, A_w, dst, K, L, nS);
