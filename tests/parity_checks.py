@@ -688,6 +688,38 @@ def check_checkpoint_interop(device, tmpdir):
     return dict(keys=len(loaded), resumed_iter=it)
 
 
+def check_x4_config_shape(device):
+    """BASELINE.json configs[2] shape in fp32 (Kvasir x4, LR 256x320, DGBs 0..13, L=256; two frames): same
+    size-independent properties as check_large_frame_x2, plus batch independence (frame 1 alone == frame 1 of the pair)."""
+    from dasr_amd import harness
+    net = DepthNet(which_ResBlk_depth=list(range(14)), in_nc=3, out_nc=3, nf=64, nb=16, scale=4, depth_latent_ch=256,
+                   depthRangeNum=10)
+    synth.closed_form_fill_(net.state_dict().items())
+    net = net.to(device)
+    lq, gt, dm, mk = [t.to(device) for t in synth.seeded_batch(0, 2, 256, 320, 4)]
+    with torch.no_grad():
+        fast = net(lq, dm, mk)
+        single = net(lq[1:], dm[1:], mk[1:])
+        graph.FORCE_GENERAL_SEAN = True
+        try:
+            general = net(lq, dm, mk)
+        finally:
+            graph.FORCE_GENERAL_SEAN = False
+    assert tuple(fast.shape) == (2, 3, 1024, 1280)
+    assert torch.equal(fast[1:], single)
+    diff = (fast - general).abs().max().item()
+    psnr = O.psnr_255(fast.cpu(), general.cpu())
+    assert diff <= 5e-4 and psnr > 90.0, (diff, psnr)
+    del general, single
+    tr = harness.Trainer(net)
+    log = tr.optimize_parameters(lq, gt, dm, mk)
+    torch.cuda.synchronize()
+    assert math.isfinite(float(log["l_all"]))
+    n_grads = sum(1 for p in net.parameters() if p.grad is not None and bool(torch.isfinite(p.grad).all()))
+    assert n_grads > 300
+    return dict(fast_vs_general=diff, psnr=psnr, loss=float(log["l_all"]), grads=n_grads)
+
+
 def check_large_frame_x2(device, H=1080, W=1920):
     """BASELINE.json configs[4] shape (EndoScene x2, one 1080p-class LR frame per GPU, L=256, DGBs 0..15): the
     oracle cannot finish this size in test time, so the checks are size-independent properties: (i) the one-hot

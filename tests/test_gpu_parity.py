@@ -135,3 +135,8 @@ def test_rccl_flat_allreduce_single_rank():
 @pytest.mark.gpu
 def test_large_frame_x2_properties():
     print(pc.check_large_frame_x2("cuda"))
+
+
+@pytest.mark.gpu
+def test_x4_config_shape_properties():
+    print(pc.check_x4_config_shape("cuda"))
