@@ -11,7 +11,7 @@ template <int MODE>   // 0: operands from registers only, 1: ds_read_b128 double
 __global__ void __launch_bounds__(512) k_loop(float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
-    for (int i = tid; i < 20 * 1024; i += 512) lds[i] = 1e-3f * (float)(i & 255);
+    for (int i = tid; i < 18 * 1024; i += blockDim.x) lds[i] = 1e-3f * (float)(i & 255);
     __syncthreads();
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
@@ -56,27 +56,33 @@ __global__ void __launch_bounds__(512) k_loop(float* out, int iters) {
 }
 
 template <int MODE>
-static void run(const char* name, float* out) {
-    const int iters = 600;
+static void run(const char* name, float* out, int threads = 512, int blocks = 256, int lds_kb = 80, int iters = 600) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_loop<MODE>, dim3(256), dim3(512), 20 * 1024 * 4, 0, out, iters);
+        hipLaunchKernelGGL(k_loop<MODE>, dim3(blocks), dim3(threads), lds_kb * 1024, 0, out, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        double flops = 256.0 * 8 * iters * 18 * 16 * (2.0 * 32 * 32 * 2);
+        double flops = (double)blocks * (threads / 64) * iters * 18 * 16 * (2.0 * 32 * 32 * 2);
         if (rep) printf("%-44s %.3f ms  %.1f TFLOP/s\n", name, ms, flops / ms / 1e9);
     }
 }
 
 int main() {
     float* out;
-    hipMalloc(&out, sizeof(float) * 256 * 512);
+    hipMalloc(&out, sizeof(float) * 2560 * 512);
     run<0>("operands resident in registers", out);
     run<1>("ds_read_b128 double-buffered (conv loop)", out);
+    // the 8-row conv tiles: two independent 256-thread workgroups per CU (73 KB of LDS each)
+    run<1>("same, 2 x 256-thread workgroups per CU", out, 256, 512, 73);
+    run<0>("registers only, 2 x 256-thread workgroups", out, 256, 512, 73);
+    // workgroup churn: the 64->64 conv's grid - 1280 workgroups of 1152 MFMAs per wave (4 chunks), 2 per CU
+    run<1>("1280 short workgroups (4 x 288 MFMAs), 2 / CU", out, 256, 1280, 73, 4);
+    run<1>("2560 short workgroups (4 x 288 MFMAs), 2 / CU", out, 256, 2560, 73, 4);
+    run<1>("640 x 512-thread workgroups (8 x 288), 1 / CU", out, 512, 1280, 95, 8);
     return 0;
 }
