@@ -443,6 +443,21 @@ def check_soft_masks_whole_net(device):
     return _compare_with_oracle(net, cfg, lq, dm, soft, device)
 
 
+def check_other_region_counts(device):
+    """depthRangeNum != 10 (the reference takes it from the yml's depthMaskNum): K = 7 and K = 16 (the kernels'
+    SEAN_MAXK), one-hot masks, nf-64 DGBs, against the oracle - forward and all gradients."""
+    out = {}
+    for K, L in ((7, 16), (16, 32)):
+        cfg = O.make_cfg(which_ResBlk_depth=[0, 1], nb=4, scale=2, depth_latent_ch=L, depthRangeNum=K)
+        net = DepthNet(which_ResBlk_depth=[0, 1], nb=4, scale=2, depth_latent_ch=L, depthRangeNum=K)
+        synth.closed_form_fill_(net.state_dict().items())
+        net = net.to(device)
+        lq, _, dm, mk = synth.closed_form_batch(1, 2, 8, 12, 2, K)
+        assert mk.shape[1] == K
+        out["K%d" % K] = _compare_with_oracle(net, cfg, lq, dm, mk, device)
+    return out
+
+
 def check_constant_alpha_and_mask_resize(device):
     """use_trainable_params=False (constant blend weights) and a depth map / masks at HALF the LR resolution:
     F.interpolate(nearest) inside SEAN (normalization.py:58-59) and the bilinear+threshold resize of the region

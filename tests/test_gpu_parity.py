@@ -140,3 +140,8 @@ def test_large_frame_x2_properties():
 @pytest.mark.gpu
 def test_x4_config_shape_properties():
     print(pc.check_x4_config_shape("cuda"))
+
+
+@pytest.mark.gpu
+def test_other_region_counts():
+    print(pc.check_other_region_counts("cuda"))

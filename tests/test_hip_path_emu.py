@@ -71,3 +71,7 @@ def test_reference_assertion(emu):
 
 def test_depth_prep(emu):
     print(pc.check_depth_prep("cpu"))
+
+
+def test_other_region_counts(emu):
+    print(pc.check_other_region_counts("cpu"))
