@@ -7,11 +7,19 @@
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int MODE>   // 0: operands from registers only, 1: ds_read_b128 double-buffered, 2: ds_read issued but unused
+template <int MODE>   // 0: operands from registers only, 1: ds_read_b128 double-buffered, 3: same with random operand bits
 __global__ void __launch_bounds__(512) k_loop(float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
-    for (int i = tid; i < 18 * 1024; i += blockDim.x) lds[i] = 1e-3f * (float)(i & 255);
+    for (int i = tid; i < 18 * 1024; i += blockDim.x) {
+        if (MODE == 3) {            // activations / weights with full-entropy mantissas, as in the real convolutions
+            unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            lds[i] = ((float)(h & 0xffffff) / 16777216.0f - 0.5f) * 2.0f;
+        } else {
+            lds[i] = 1e-3f * (float)(i & 255);
+        }
+    }
     __syncthreads();
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
@@ -43,9 +51,9 @@ __global__ void __launch_bounds__(512) k_loop(float* out, int iters) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll 1
         for (int j = 0; j < 18; j += 2) {
-            if (MODE == 1) ld(j + 1, A1, B1);
+            if (MODE == 1 || MODE == 3) ld(j + 1, A1, B1);
             mma(A0, B0);
-            if (MODE == 1) ld(j + 2, A0, B0);
+            if (MODE == 1 || MODE == 3) ld(j + 2, A0, B0);
             mma(A1, B1);
         }
     }
@@ -77,6 +85,8 @@ int main() {
     hipMalloc(&out, sizeof(float) * 2560 * 512);
     run<0>("operands resident in registers", out);
     run<1>("ds_read_b128 double-buffered (conv loop)", out);
+    run<3>("same, random operand bits (power)", out, 512, 256, 80, 6000);
+    run<1>("same, regular operand bits, long run", out, 512, 256, 80, 6000);
     // the 8-row conv tiles: two independent 256-thread workgroups per CU (73 KB of LDS each)
     run<1>("same, 2 x 256-thread workgroups per CU", out, 256, 512, 73);
     run<0>("registers only, 2 x 256-thread workgroups", out, 256, 512, 73);
