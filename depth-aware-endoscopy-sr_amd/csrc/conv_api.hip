@@ -37,6 +37,29 @@ extern "C" int dasr_conv2d_fwd(const float* x, const float* w, const float* bias
     return conv_direct_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
 }
 
+// conv 3x3 / stride 1 / pad 1 (+bias) and the InstanceNorm statistics of its output in one pass (the DGB convs)
+extern "C" size_t dasr_conv2d_fwd_stats_workspace(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    ConvGeom g{B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 0};
+    size_t fused = conv_mfma_fwd_stats_supported(g) ? conv_mfma_fwd_stats_workspace(g) : 0;
+    size_t plain = dasr_instnorm_stats_workspace(B, H * W, Cout);
+    return fused > plain ? fused : plain;
+}
+extern "C" int dasr_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* mean, float* var,
+                                     void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
+                                     void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(w); DASR_CHECK_PTR(y); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var);
+    DASR_CHECK_PTR(workspace);
+    ConvGeom g{B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 0};
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (workspace_bytes < dasr_conv2d_fwd_stats_workspace(B, H, W, Cin, Cout)) return DASR_E_WORKSPACE;
+    if (conv_mfma_fwd_stats_supported(g)) return conv_mfma_fwd_stats(g, x, w, bias, y, mean, var, workspace, stream);
+    rc = dasr_conv2d_fwd(x, w, bias, nullptr, y, B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 0, DASR_ACT_NONE, 1, stream);
+    if (rc) return rc;
+    return dasr_instnorm_stats(y, mean, var, workspace, workspace_bytes, B, H * W, Cout, stream);
+}
+
 extern "C" int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, int B, int Ho, int Wo, int Cout,
                                         int act, int ps_r, void* stream) {
     DASR_CHECK_PTR(dy); DASR_CHECK_PTR(y); DASR_CHECK_PTR(dconv);

@@ -27,6 +27,10 @@ int conv_colsum(const float* m, float* out, size_t rows, int C, void* stream);
 
 // conv_mfma.hip (3x3, stride 1, pad 1, channel counts multiples of 16/32)
 bool conv_mfma_supported(const ConvGeom& g);
+bool conv_mfma_fwd_stats_supported(const ConvGeom& g);
+size_t conv_mfma_fwd_stats_workspace(const ConvGeom& g);
+int conv_mfma_fwd_stats(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, float* mean,
+                        float* var, void* workspace, void* stream);
 bool conv_mfma_dgrad_supported(const ConvGeom& g);
 bool conv_mfma_wgrad_supported(const ConvGeom& g);
 int conv_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,

@@ -59,6 +59,10 @@ struct ConvMfmaArgs {
     // write the gradient w.r.t. the producing conv's raw output directly (no separate epilogue-backward pass)
     const float* mask_src;
     int mask_act, unps_r;
+    // forward only, optional: per-tile instance-norm partials of the (pre-activation) output, [B][tiles][Cout][2] =
+    // (mean, M2) of the tile's pixels per channel; every tile must take the fast epilogue (W % 32 == 0, act / residual /
+    // PixelShuffle off) - conv_mfma_fwd_stats checks that
+    float* stats_part;
 };
 
 // CM_TH = tile rows = 2 x waves per workgroup (8 rows / 256 threads, or 16 rows / 512 threads: the 16-row tile
@@ -256,6 +260,63 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
                 }
             }
         }
+        if (a.stats_part) {
+            // InstanceNorm statistics of this tile, fused (nn.InstanceNorm2d after the DGB convs, sftmd_arch.py:813): a
+            // lane holds 32 pixels (2 rows x 16) of channel co; two-pass (mean, M2) in registers, then Chan merges:
+            // with the other half-wave (shuffle), across the waves (LDS), and later across tiles (k_instnorm_merge_tiles).
+            float* sStat = (float*)smem;                           // [waves][NTILE][2]; the MFMA operands are dead by now
+            const int rows = (y0 + 2 * wvu < a.H ? 1 : 0) + (y0 + 2 * wvu + 1 < a.H ? 1 : 0);
+            float mean_l[NT], m2_l[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float bv = a.bias ? a.bias[n0 + 32 * n + li] : 0.f;
+                float sum = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    if (y0 + 2 * wvu + m < a.H)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum += acc[m][n][r] + bv;
+                const float mu = rows ? sum / (16.f * (float)rows) : 0.f;
+                float q = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    if (y0 + 2 * wvu + m < a.H)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float d = acc[m][n][r] + bv - mu;
+                            q = fmaf(d, d, q);
+                        }
+                // the other half-wave holds the same channel, the same number of (other) pixels: equal-count Chan merge
+                const float mu2 = __shfl_xor(mu, 32, 64), q2 = __shfl_xor(q, 32, 64);
+                const float dlt = mu2 - mu;
+                mean_l[n] = 0.5f * (mu + mu2);
+                m2_l[n] = q + q2 + dlt * dlt * (8.f * (float)rows);      // n1*n2/(n1+n2) = 16*rows/2
+            }
+            __syncthreads();                                       // every wave is done with the last chunk's LDS reads
+            if (lh == 0) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    sStat[(wv * NTILE + 32 * n + li) * 2 + 0] = mean_l[n];
+                    sStat[(wv * NTILE + 32 * n + li) * 2 + 1] = m2_l[n];
+                }
+            }
+            __syncthreads();
+            if (tid < NTILE) {
+                float cnt = 0.f, mu = 0.f, m2 = 0.f;
+                for (int w = 0; w < NTHR / 64; ++w) {
+                    const int rw = (y0 + 2 * w < a.H ? 1 : 0) + (y0 + 2 * w + 1 < a.H ? 1 : 0);
+                    if (rw == 0) continue;
+                    const float nb = 32.f * (float)rw, mb = sStat[(w * NTILE + tid) * 2], m2b = sStat[(w * NTILE + tid) * 2 + 1];
+                    const float tot = cnt + nb, delta = mb - mu;
+                    mu += delta * (nb / tot);
+                    m2 += m2b + delta * delta * (cnt * nb / tot);
+                    cnt = tot;
+                }
+                float* dst = a.stats_part + (((size_t)b * (tiles_x * tiles_y) + tile) * a.Cout + n0 + tid) * 2;
+                dst[0] = mu;
+                dst[1] = m2;
+            }
+        }
         CM_T_MARK(6);
         CM_T_FLUSH();
         return;
@@ -308,6 +369,12 @@ bool conv_mfma_supported(const ConvGeom& g) {
            (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
 }
 
+static int cm_tile_rows(int B, int H, int W, int Cout) {
+    const bool nt2 = (Cout % 64) == 0;
+    const long wg16 = (long)((W + CM_TW - 1) / CM_TW) * ((H + 15) / 16) * B * (Cout / (nt2 ? 64 : 32));
+    return ((H % 16) == 0 && (wg16 % 256 == 0 || wg16 >= 2048)) ? 16 : 8;
+}
+
 template <int WMODE>
 static int launch_conv_mfma(ConvMfmaArgs& a, void* stream) {
     // 16-row tiles (one 512-thread workgroup per CU) stage every weight slice once for twice the pixels; 8-row
@@ -315,8 +382,7 @@ static int launch_conv_mfma(ConvMfmaArgs& a, void* stream) {
     // other's matrix work and halve the tail.  Measured (B=16): 16 rows win when the 16-row grid fills whole rounds
     // of the 256 CUs or is many rounds long, 8 rows win otherwise (64->64 at 128x160: 264 -> 238 us).
     const bool nt2 = (a.Cout % 64) == 0;
-    const long wg16 = (long)((a.W + CM_TW - 1) / CM_TW) * ((a.H + 15) / 16) * a.B * (a.Cout / (nt2 ? 64 : 32));
-    const int TH = ((a.H % 16) == 0 && (wg16 % 256 == 0 || wg16 >= 2048)) ? 16 : 8;
+    const int TH = cm_tile_rows(a.B, a.H, a.W, a.Cout);
     int tiles = ((a.W + CM_TW - 1) / CM_TW) * ((a.H + TH - 1) / TH);
     const int G8 = (tiles * a.B + 7) / 8 * 8;                 // pixel tiles, padded to whole rounds over the 8 XCDs
     const dim3 grid(G8 * (a.Cout / (nt2 ? 64 : 32)));
@@ -337,15 +403,65 @@ static int launch_conv_mfma(ConvMfmaArgs& a, void* stream) {
 
 int conv_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
                   float* y, int act, int ps_r, void* stream) {
-    ConvMfmaArgs a{x, w, bias, residual, y, g.B, g.H, g.W, g.Cin, g.Cout, act, ps_r, 0, nullptr, 0, 1};
+    ConvMfmaArgs a{x, w, bias, residual, y, g.B, g.H, g.W, g.Cin, g.Cout, act, ps_r, 0, nullptr, 0, 1, nullptr};
     return launch_conv_mfma<0>(a, stream);
+}
+
+// ---- forward + InstanceNorm statistics of the output (the DGB convs) -------------------------------------------------
+static int conv_mfma_tile_rows(const ConvGeom& g) { return cm_tile_rows(g.B, g.H, g.W, g.Cout); }
+bool conv_mfma_fwd_stats_supported(const ConvGeom& g) { return conv_mfma_supported(g) && (g.W % CM_TW) == 0; }
+size_t conv_mfma_fwd_stats_workspace(const ConvGeom& g) {
+    const int th = conv_mfma_tile_rows(g);
+    return sizeof(float) * 2 * (size_t)g.B * (g.W / CM_TW) * ((g.H + th - 1) / th) * g.Cout;
+}
+// mean / var per (b, c) from the per-tile (mean, M2) records: the same Chan recurrence as k_instnorm_merge, tile by tile
+__global__ void __launch_bounds__(256) k_instnorm_merge_tiles(const float* __restrict__ part, float* __restrict__ mean,
+                                                              float* __restrict__ var, int H, int W, int C, int th,
+                                                              int tiles_x, int tiles_y, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = i % C, b = i / C, nt = tiles_x * tiles_y;
+    float cnt = 0.f, mu = 0.f, m2 = 0.f;
+    for (int k0 = 0; k0 < nt; k0 += 16) {
+        float2 rec[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = k0 + u < nt ? k0 + u : nt - 1;
+            rec[u] = *(const float2*)(part + (((size_t)b * nt + k) * C + c) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = k0 + u;
+            if (k >= nt) break;
+            const int ty = k / tiles_x;
+            const int rows = (ty + 1) * th <= H ? th : H - ty * th;
+            const float nb = (float)(rows * CM_TW);
+            const float tot = cnt + nb, delta = rec[u].x - mu;
+            mu += delta * (nb / tot);
+            m2 += rec[u].y + delta * delta * (cnt * nb / tot);
+            cnt = tot;
+        }
+    }
+    mean[i] = mu;
+    var[i] = m2 / (float)(H * W);
+}
+int conv_mfma_fwd_stats(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, float* mean,
+                        float* var, void* workspace, void* stream) {
+    ConvMfmaArgs a{x, w, bias, nullptr, y, g.B, g.H, g.W, g.Cin, g.Cout, DASR_ACT_NONE, 1, 0, nullptr, 0, 1,
+                   (float*)workspace};
+    int rc = launch_conv_mfma<0>(a, stream);
+    if (rc) return rc;
+    const int th = conv_mfma_tile_rows(g), n = g.B * g.Cout;
+    DASR_LAUNCH(k_instnorm_merge_tiles, dim3(dasr_cdiv((size_t)n, 256)), dim3(256), 0, stream, (const float*)workspace, mean,
+                var, g.H, g.W, g.Cout, th, g.W / CM_TW, (g.H + th - 1) / th, n);
+    DASR_RETURN_LAUNCH_STATUS();
 }
 
 // dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * W[tap][ci][co]: a 3x3 conv of dconv (channels Cout) to Cin
 int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate,
                     const float* mask_src, int mask_act, int unps_r, void* stream) {
     ConvMfmaArgs a{dconv, w, nullptr, nullptr, dx, g.B, g.H, g.W, g.Cout, g.Cin, DASR_ACT_NONE, 1, accumulate,
-                   mask_src, mask_act, unps_r < 1 ? 1 : unps_r};
+                   mask_src, mask_act, unps_r < 1 ? 1 : unps_r, nullptr};
     return launch_conv_mfma<1>(a, stream);
 }
 bool conv_mfma_dgrad_supported(const ConvGeom& g) {

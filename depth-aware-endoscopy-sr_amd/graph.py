@@ -29,6 +29,7 @@ SIDE_STREAM = True
 # run on a third stream and fill whatever the data-gradient chain leaves idle.
 import os as _os
 TAIL_WGRAD_SIDE = False  # weight gradients of the HR tail on the (then idle) depth-branch stream; see conv(side_wgrad=)
+FUSE_INSTNORM_STATS = False  # measured: 115.5 -> 111.5 frames/s when on (two more barriers + reductions in the 64->64 conv epilogue cost more than the statistics pass they replace); the entry point stays, tested
 WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
 
@@ -141,12 +142,20 @@ def bias_pair(tape, ba, bb):
 
 
 def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.ACT_NONE, ps_r=1, residual=None,
-         side_wgrad=False):
-    y = ops.conv2d_fwd(x.data, w.data, bias.data if bias is not None else None,
-                       residual.data if residual is not None else None, stride, pad, transposed, act, ps_r)
+         side_wgrad=False, want_stats=False):
+    stats = None
+    if (want_stats and FUSE_INSTNORM_STATS and act == ops.ACT_NONE and ps_r == 1 and residual is None and stride == 1 and
+            pad == 1 and not transposed and tuple(w.data.shape[1:3]) == (3, 3)):
+        # the InstanceNorm statistics of the output come out of the convolution's epilogue (no second pass over y)
+        y, mean, var = ops.conv2d_fwd_stats(x.data, w.data, bias.data if bias is not None else None)
+        stats = (mean, var)
+    else:
+        y = ops.conv2d_fwd(x.data, w.data, bias.data if bias is not None else None,
+                           residual.data if residual is not None else None, stride, pad, transposed, act, ps_r)
     needs = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad) or \
         (residual is not None and residual.requires_grad)
     out = Var(y, needs)
+    out.stats = stats
     x.uses += 1
     if residual is not None:
         residual.uses += 1
@@ -282,7 +291,7 @@ def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, 
     if gb2.event is not None:                # gamma2/beta2 were computed on the side stream
         torch.cuda.current_stream().wait_event(gb2.event)
         gb2.data.record_stream(torch.cuda.current_stream())
-    mean, var = ops.instnorm_stats(t.data)
+    mean, var = t.stats if t.stats is not None else ops.instnorm_stats(t.data)
     y = ops.sean_fwd(t.data, mean, var, gb2.data, mask.planes, mask.region, mask.flag, D.data, bias_g.data, bias_b.data,
                      alpha_g.data, alpha_b.data, residual.data if residual is not None else None, relu)
     out = Var(y, True)
@@ -405,9 +414,9 @@ def depth_block(tape, P, name, x, depth_map, mask, st, consts, gb2_pair=None):
     B, H, W, C = x.data.shape
     depth_map, mask = block_depth_inputs((H, W), depth_map, mask)
     g1, g2 = gb2_pair if gb2_pair is not None else (None, None)
-    t1 = conv(tape, x, pack(tape, P[name + ".conv1.0.weight"]), P[name + ".conv1.0.bias"])
+    t1 = conv(tape, x, pack(tape, P[name + ".conv1.0.weight"]), P[name + ".conv1.0.bias"], want_stats=True)
     a = sean(tape, P, name + ".norm1", t1, depth_map, mask, st, None, True, consts, g1)
-    t2 = conv(tape, a, pack(tape, P[name + ".conv2.0.weight"]), P[name + ".conv2.0.bias"])
+    t2 = conv(tape, a, pack(tape, P[name + ".conv2.0.weight"]), P[name + ".conv2.0.bias"], want_stats=True)
     return sean(tape, P, name + ".norm2", t2, depth_map, mask, st, x, True, consts, g2)
 
 

@@ -220,6 +220,21 @@ def conv2d_wgrad_act(x, dy, y, w_shape, act, stride=1, pad=1, transposed=False, 
     return dw, db
 
 
+def conv2d_fwd_stats(x, w, bias):
+    """3x3 / stride 1 / pad 1 conv (+bias) and the InstanceNorm statistics of its output: (y, mean[B,C], var[B,C])."""
+    B, H, W, Cin = x.shape
+    KH, KW, Cin2, Cout = w.shape[1:]
+    assert (KH, KW) == (3, 3) and Cin2 == Cin
+    y = empty((B, H, W, Cout), x)
+    mean = empty((B, Cout), x)
+    var = empty((B, Cout), x)
+    nbytes = int(_lib.get().dasr_conv2d_fwd_stats_workspace(B, H, W, Cin, Cout))
+    ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
+    _call("dasr_conv2d_fwd_stats", _p(x), _p(w), _p(bias, True), _p(y), _p(mean), _p(var), _p(ws), nbytes, B, H, W, Cin,
+          Cout)
+    return y, mean, var
+
+
 # ---- instance norm / SEAN -------------------------------------------------------------------
 def instnorm_stats(x):
     B, H, W, C = x.shape

@@ -12,7 +12,7 @@ from . import ops
 class Var:
     """A device tensor plus its gradient slot."""
     __slots__ = ("data", "grad", "requires_grad", "name", "uses", "epilogue", "grad_is_preact", "event",
-                 "grad_event")
+                 "grad_event", "stats")
 
     def __init__(self, data, requires_grad=False, name=None):
         self.data = data
@@ -24,6 +24,7 @@ class Var:
         self.grad_is_preact = False  # the consumer already applied the epilogue backward (dasr_conv2d_dgrad_act)
         self.event = None            # HIP event after the producing kernel when it ran on another stream
         self.grad_event = None       # HIP event after the kernel that produced .grad on another stream
+        self.stats = None            # (mean, var) per (b, c) when the producing conv computed them in its epilogue
 
     @property
     def shape(self):

@@ -91,6 +91,16 @@ int dasr_weight_pack_bwd(const float* dw_hwio, const float* v, const float* g, c
 int dasr_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, const float* residual, float* y, int B,
                     int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                     int transposed, int act, int ps_r, void* stream);
+/* dasr_conv2d_fwd for a 3x3 / stride 1 / pad 1 convolution with bias and no activation, PLUS the statistics
+ * nn.InstanceNorm2d(affine=False) needs of its output (sftmd_arch.py:811-820: `conv1 = Sequential(Conv2d, InstanceNorm2d)`):
+ * mean[b,c], var[b,c] (biased) over the H*W pixels, as dasr_instnorm_stats(y) returns them.  On the MFMA path the
+ * per-tile (mean, M2) pairs come out of the convolution's epilogue (no second pass over y) and are merged in tile
+ * order with Chan's update; other shapes run the two entry points back to back.
+ * workspace: dasr_conv2d_fwd_stats_workspace() bytes. */
+size_t dasr_conv2d_fwd_stats_workspace(int B, int H, int W, int Cin, int Cout);
+int dasr_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* mean, float* var,
+                          void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
+
 /* Backward of the epilogue: dconv[b,oy,ox,cc] = dy[...shuffled...] * act'(y[...]) (y = saved forward output). */
 int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, int B, int Ho, int Wo, int Cout, int act,
                              int ps_r, void* stream);

@@ -772,3 +772,28 @@ def check_large_frame_x2(device, H=1080, W=1920):
             n_grads += 1
     assert n_grads > 300
     return dict(fast_vs_general=diff, psnr=psnr, loss=float(log["l_all"]), grads=n_grads)
+
+
+def check_conv_fwd_stats(device):
+    """dasr_conv2d_fwd_stats: the convolution output is bit-identical to dasr_conv2d_fwd and the statistics match
+    dasr_instnorm_stats of that output (and torch's biased variance), on the fused path (W % 32 == 0: 8- and 16-row
+    tiles, ragged last tile row, 32 / 64 / 128 channels) and on the fallback (W % 32 != 0, Cin not a multiple of 16)."""
+    worst = 0.0
+    for (B, H, W, Cin, Cout) in ((2, 16, 32, 64, 64), (1, 21, 64, 64, 64), (2, 40, 32, 32, 32), (1, 32, 96, 128, 128),
+                                 (2, 9, 20, 64, 64), (1, 16, 32, 8, 32)):
+        g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin)
+        x = (torch.rand(B, H, W, Cin, generator=g) - 0.4).to(device)
+        wt = ops.pack_hwio(((torch.rand(3, 3, Cin, Cout, generator=g) - 0.5) * 0.2).to(device))
+        bias = (torch.rand(Cout, generator=g) - 0.5).to(device)
+        y0 = ops.conv2d_fwd(x, wt, bias)
+        m0, v0 = ops.instnorm_stats(y0)
+        y1, m1, v1 = ops.conv2d_fwd_stats(x, wt, bias)
+        assert torch.equal(y0, y1), (B, H, W, Cin, Cout)
+        yt = y0.double().reshape(B, H * W, Cout).cpu()
+        mt, vt = yt.mean(1), yt.var(1, unbiased=False)
+        for got_m, got_v in ((m0, v0), (m1, v1)):
+            em = ((got_m.cpu().double() - mt).abs() / (mt.abs() + vt.sqrt())).max().item()
+            ev = ((got_v.cpu().double() - vt).abs() / vt).max().item()
+            assert em <= 2e-6 and ev <= 2e-5, (B, H, W, Cin, Cout, em, ev)
+            worst = max(worst, em, ev)
+    return dict(worst_rel=worst)

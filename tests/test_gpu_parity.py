@@ -145,3 +145,8 @@ def test_x4_config_shape_properties():
 @pytest.mark.gpu
 def test_other_region_counts():
     print(pc.check_other_region_counts("cuda"))
+
+
+@pytest.mark.gpu
+def test_conv_fwd_stats():
+    print(pc.check_conv_fwd_stats("cuda"))

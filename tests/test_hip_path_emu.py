@@ -75,3 +75,7 @@ def test_depth_prep(emu):
 
 def test_other_region_counts(emu):
     print(pc.check_other_region_counts("cpu"))
+
+
+def test_conv_fwd_stats(emu):
+    print(pc.check_conv_fwd_stats("cpu"))
