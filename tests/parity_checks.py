@@ -136,10 +136,17 @@ def check_conv_variants(device, seed=0):
         (8, 32, 3, 1, 1, False, 1, 1, False, 7, 9),
         (64, 64, 3, 1, 1, False, 2, 1, False, 16, 33), (32, 32, 3, 1, 1, False, 1, 1, True, 32, 20),
         (16, 128, 3, 1, 1, False, 2, 2, False, 16, 40),
+        # full-width tiles (fast epilogue), 16-row tiles, several N slices, a tile count that is not a multiple of 8
+        # (padded workgroups of the XCD-aware order), residual / PixelShuffle through the fast epilogue, the 32x128
+        # and 64x32 wgrad blocks
+        (128, 128, 3, 1, 1, False, 0, 1, False, 16, 32, 3), (64, 256, 3, 1, 1, False, 2, 2, False, 32, 64, 1),
+        (32, 64, 3, 1, 1, False, 1, 1, False, 48, 32, 2), (64, 64, 3, 1, 1, False, 0, 1, True, 16, 64, 2),
+        (64, 32, 3, 1, 1, False, 2, 1, False, 16, 32, 2), (32, 128, 3, 1, 1, False, 2, 2, False, 16, 32, 2),
     ]
     worst = 0.0
-    for (cin, cout, k, stride, pad, tr, act, ps, res, H, W) in cases:
-        B = 2
+    for case in cases:
+        (cin, cout, k, stride, pad, tr, act, ps, res, H, W) = case[:11]
+        B = case[11] if len(case) > 11 else 2
         x = rn(B, cin, H, W).requires_grad_(True)
         wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
         v = rn(*wshape).requires_grad_(True)
