@@ -498,8 +498,12 @@ __global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const fl
     const int c = live ? c0 + 4 * cq : 0;                      // dead lanes (C % 64 != 0) shadow channel 0, never store
     // Persistent workgroup: a contiguous chunk of (sample, tile) pairs; D[b] is restaged only when the sample
     // changes, so its 50 KB L2->LDS copy is paid about once per workgroup instead of once per tile.
-    const int first = blockIdx.x * tiles_per_wg;
-    int last = first + tiles_per_wg;
+    // tiles_per_wg packs (base, rem): the first `rem` workgroups take base + 1 consecutive tiles, the others base, so
+    // that ALL 768 resident slots are used and every CU ends up with the same number of tiles (640 equal workgroups
+    // left CUs with 4 or 6 tiles at B = 16)
+    const int base = tiles_per_wg >> 16, rem = tiles_per_wg & 0xffff;
+    const int first = blockIdx.x * base + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    int last = first + base + ((int)blockIdx.x < rem ? 1 : 0);
     if (last > g.B * tiles_per_sample) last = g.B * tiles_per_sample;
     if (first >= last) return;
     auto tile_of = [&](int tt) {
@@ -818,11 +822,13 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
     if (fast) {
         int tiles = B * ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
         int slices = (int)dasr_cdiv(C, 64);
-        int per = (tiles * slices + 767) / 768;            // 256 CUs x 3 resident workgroups (51 KB of LDS each)
-        if (per < 1) per = 1;
+        int nwg = 768 / slices;                             // 256 CUs x 3 resident workgroups (51 KB of LDS each)
+        if (nwg < 1) nwg = 1;
+        if (nwg > tiles) nwg = tiles;
+        const int per = ((tiles / nwg) << 16) | (tiles % nwg);      // (base, rem), see the kernel; rem < nwg <= 768
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
 #define SEAN_FWD_GO(RELU, RES)                                                                                     \
-    DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES>), dim3((tiles + per - 1) / per, slices), dim3(256), lds, stream, g, t,  \
+    DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES>), dim3(nwg, slices), dim3(256), lds, stream, g, t,                        \
                 mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, eps, per)
         if (relu) { if (residual) SEAN_FWD_GO(true, true); else SEAN_FWD_GO(true, false); }
         else      { if (residual) SEAN_FWD_GO(false, true); else SEAN_FWD_GO(false, false); }
