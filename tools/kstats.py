@@ -9,8 +9,8 @@ import sys
 
 d = sys.argv[1]
 agg = collections.defaultdict(lambda: [0, 0.0])
-csvs = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)
-dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+csvs = sorted(glob.glob(d + "/**/*_kernel_trace.csv", recursive=True), key=lambda f: __import__("os").path.getmtime(f))[-1:]   # newest run only
+dbs = sorted(glob.glob(d + "/**/*_results.db", recursive=True), key=lambda f: __import__("os").path.getmtime(f))[-1:]
 if csvs:
     for r in csv.DictReader(open(csvs[0])):
         key = (r["Kernel_Name"].split("(")[0][:44], r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
