@@ -99,6 +99,27 @@ extern "C" int dasr_resize_nearest_nchw(const float* src, float* dst, int BC, in
     DASR_RETURN_LAUNCH_STATUS();
 }
 
+// the same index map on the region bytes of one-hot masks (nearest resize commutes with the one-hot encoding)
+__global__ void k_resize_nearest_u8(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int h, int w,
+                                    int H, int W) {
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int Y = blockIdx.y, b = blockIdx.z;
+    int y = (int)floorf((float)Y * sh); if (y > h - 1) y = h - 1;
+    const unsigned char* row = src + ((size_t)b * h + y) * w;
+    unsigned char* out = dst + ((size_t)b * H + Y) * W;
+    for (int X = blockIdx.x * blockDim.x + threadIdx.x; X < W; X += gridDim.x * blockDim.x) {
+        int x = (int)floorf((float)X * sw); if (x > w - 1) x = w - 1;
+        out[X] = row[x];
+    }
+}
+extern "C" int dasr_resize_nearest_u8(const unsigned char* src, unsigned char* dst, int B, int h, int w, int H, int W,
+                                      void* stream) {
+    DASR_CHECK_PTR(src); DASR_CHECK_PTR(dst);
+    DASR_CHECK_SHAPE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && H <= 65535 && B <= 65535);
+    DASR_LAUNCH(k_resize_nearest_u8, dim3(dasr_cdiv((size_t)W, 256), H, B), dim3(256), 0, stream, src, dst, h, w, H, W);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+
 __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = a[i] + b[i];

@@ -12,6 +12,7 @@ which launches HIP kernels through the C ABI; gradients come from the tape's han
 backward, bridged into ``torch.autograd`` by one ``autograd.Function`` so that the reference's
 losses, ``loss.backward()`` and ``torch.optim.Adam`` work as before.
 """
+import contextlib
 import math
 
 import torch
@@ -129,11 +130,17 @@ class _Encoder(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # autograd bridge
 # ---------------------------------------------------------------------------------------------
+def _device_guard(t):
+    """Kernels launch on the current stream of the CURRENT device: make that the tensors' device (a net on cuda:1
+    called while cuda:0 is current, nn.DataParallel worker threads, autograd's backward threads)."""
+    return torch.cuda.device(t.device) if t.is_cuda else contextlib.nullcontext()
+
+
 class _DepthNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, inp, depth_map, depth_mask, region, *params):
         tape = Tape(enabled=True)
-        pvars = [Var(p.detach(), p.requires_grad, name) for (name, _), p in zip(net._param_items, params)]
+        pvars = [Var(p.detach(), p.requires_grad, name) for name, p in zip(net._param_names, params)]
         P = {v.name: v for v in pvars}
         out = graph.depthnet_forward(tape, P, net.cfg, net._consts(inp.device), inp.detach().contiguous(),
                                      depth_map.detach().contiguous(), depth_mask.detach().contiguous(), region)
@@ -146,7 +153,8 @@ class _DepthNetFunction(torch.autograd.Function):
         if tape is None:
             raise RuntimeError("DepthNet: backward called twice on the same forward")
         out.grad = dout.contiguous()
-        tape.backward()
+        with _device_guard(dout):
+            tape.backward()
         grads = tuple(v.grad for v in pvars)
         # drop every other reference to the gradient tensors: autograd's AccumulateGrad then adopts them as
         # `param.grad` instead of cloning each one (~300 extra copy kernels per step otherwise)
@@ -196,6 +204,11 @@ class DepthNet(nn.Module):
                                       nn.LeakyReLU(0.2, inplace=True))
         self.conv_output = _PlainConv(32, out_nc, 9)
         self._const_cache = {}
+        # Parameter names in registration order, fixed here.  forward() resolves them through the module tree's
+        # ATTRIBUTES, not named_parameters(): an nn.DataParallel replica keeps its (broadcast, non-leaf) weights as
+        # plain attributes and exposes no parameters at all (torch >= 1.5, torch/nn/parallel/replicate.py).
+        self._param_names = tuple(name for name, _ in self.named_parameters())
+        self._param_paths = tuple(tuple(name.split(".")) for name in self._param_names)
 
     # constants used when the blend weights are not trainable (normalization.py:33-35)
     def _consts(self, device):
@@ -207,13 +220,27 @@ class DepthNet(nn.Module):
             }
         return self._const_cache[key]
 
-    @property
-    def _param_items(self):
-        return list(self.named_parameters())
+    def _resolve_params(self):
+        """This module's (or this replica's) weight tensors, in ``_param_names`` order."""
+        out = []
+        for path in self._param_paths:
+            mod = self
+            for part in path[:-1]:
+                mod = mod._modules[part]
+            out.append(getattr(mod, path[-1]))
+        return out
 
     def forward(self, input, depthMap, depthMask):
-        items = self._param_items
-        params = [p for _, p in items]
+        with _device_guard(input):
+            return self._forward(input, depthMap, depthMask)
+
+    def _forward(self, input, depthMap, depthMask):
+        params = self._resolve_params()
+        for t, nm in ((depthMap, "depthMap"), (depthMask, "depthMask")):
+            if t.device != input.device:
+                raise ValueError("DepthNet: %s is on %s, input on %s" % (nm, t.device, input.device))
+        if params and params[0].device != input.device:
+            raise ValueError("DepthNet: parameters on %s, input on %s" % (params[0].device, input.device))
         for t, nm in ((input, "input"), (depthMap, "depthMap"), (depthMask, "depthMask")):
             if t.dtype != torch.float32:
                 raise TypeError("DepthNet: %s must be float32" % nm)
@@ -221,9 +248,7 @@ class DepthNet(nn.Module):
             raise ValueError("DepthNet: expected 4-D NCHW tensors")
         # masks prepared on the device (dasr_amd.prep.depth_to_masks) carry their region bytes: no compression pass,
         # no host read-back of the one-hot flag
-        region = getattr(depthMask, "_dasr_region", None)
-        if region is not None and tuple(region.shape) != (depthMask.shape[0],) + tuple(depthMask.shape[2:]):
-            region = None
+        region = graph.attached_region(depthMask)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _DepthNetFunction.apply(self, input, depthMap, depthMask, region, *params)
         tape = Tape(enabled=False)
@@ -231,7 +256,7 @@ class DepthNet(nn.Module):
             if not hasattr(self, "_fold_cache"):
                 object.__setattr__(self, "_fold_cache", {})
             tape.fold_cache = self._fold_cache
-        P = {name: Var(p.detach(), False, name) for name, p in items}
+        P = {name: Var(p.detach(), False, name) for name, p in zip(self._param_names, params)}
         out = graph.depthnet_forward(tape, P, self.cfg, self._consts(input.device), input.detach().contiguous(),
                                      depthMap.detach().contiguous(), depthMask.detach().contiguous(), region)
         return out.data

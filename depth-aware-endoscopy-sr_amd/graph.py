@@ -53,6 +53,7 @@ def _folded(tape, key, tensors, make):
     if tape.enabled or cache is None or key is None:
         return make()
     ver = tuple((t.data_ptr(), t._version) for t in tensors)
+    key = key + (str(tensors[0].device),)      # DataParallel replicas share the cache dict, one entry per device
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -323,26 +324,54 @@ def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, 
 FORCE_GENERAL_SEAN = False
 
 
+def attached_region(mask):
+    """Region bytes that dasr_amd.prep.depth_to_masks attached to a mask tensor, or None.  They are trusted only while
+    the tensor is unmodified: an in-place edit (a flip, a crop written back) bumps torch's version counter."""
+    region = getattr(mask, "_dasr_region", None)
+    if region is None:
+        return None
+    if tuple(region.shape) != (mask.shape[0],) + tuple(mask.shape[2:]) or region.device != mask.device:
+        return None
+    if getattr(mask, "_dasr_version", None) != mask._version:
+        return None
+    return region
+
+
 class MaskPack:
     """The depth masks as the reference delivers them ([B,K,H,W] float planes) plus their compressed form
-    (one region byte per pixel and a device-side "not one-hot" flag, dasr_mask_compress)."""
-    __slots__ = ("planes", "region", "flag")
+    (one region byte per pixel and a device-side "not one-hot" flag, dasr_mask_compress).
 
-    def __init__(self, planes, region=None):
+    The host never reads the flag: with (region, flag) both set every SEAN call launches the gather kernel and the
+    general kernel and the flag decides ON THE DEVICE which of them works (the other returns at once); masks prepared
+    by prep.depth_to_masks are one-hot by construction (flag None: gather kernel only)."""
+    __slots__ = ("planes", "region", "flag", "_resized")
+
+    def __init__(self, planes, region=None, flag=None):
         self.planes = planes
+        self._resized = {}
         if FORCE_GENERAL_SEAN:               # tests: run the soft-mask kernels on one-hot masks (independent code path)
             self.region, self.flag = None, None
             return
-        if region is not None:               # prepared on the device (prep.depth_to_masks): one-hot by construction
-            self.region, self.flag = region, None
+        if region is not None:               # prepared on the device (one-hot by construction) or resized from a pack
+            self.region, self.flag = region, flag
             return
-        region, flag = ops.mask_compress(planes)
-        # one 4-byte read-back per forward: lets every SEAN call launch exactly one kernel.  (Pass the device flag
-        # through instead - both kernels launched, decision on the device - if the forward must not synchronise.)
-        if int(flag.item()) == 0:
-            self.region, self.flag = region, None
-        else:
-            self.region, self.flag = None, None
+        self.region, self.flag = ops.mask_compress(planes)
+
+    def resized(self, H, W):
+        """F.interpolate(mask, mode='nearest') at a block's feature size (normalization.py:59), once per size per
+        forward.  The region bytes are resized themselves (no second compression pass): nearest resize commutes with
+        the one-hot encoding, and a pack that is not one-hot keeps its flag."""
+        if tuple(self.planes.shape[2:]) == (H, W):
+            return self
+        hit = self._resized.get((H, W))
+        if hit is None:
+            planes = ops.resize_nearest_nchw(self.planes, H, W)
+            if self.region is None:
+                hit = MaskPack(planes)
+            else:
+                hit = MaskPack(planes, ops.resize_nearest_u8(self.region, H, W), self.flag)
+            self._resized[(H, W)] = hit
+        return hit
 
     @property
     def shape(self):
@@ -405,7 +434,7 @@ def block_depth_inputs(x_hw, depth_map, mask):
     if tuple(depth_map.data.shape[1:3]) != (H, W):
         d = ops.resize_nearest_nchw(depth_map.data.view(B, 1, *depth_map.data.shape[1:3]), H, W)
         depth_map = Var(d.view(B, H, W, 1))
-        mask = MaskPack(ops.resize_nearest_nchw(mask.planes, H, W))
+        mask = mask.resized(H, W)
     return depth_map, mask
 
 

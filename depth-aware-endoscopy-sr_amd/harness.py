@@ -32,6 +32,14 @@ def cosine_restart_lr(step, base_lr=1e-3, T_period=(20000, 20000, 20000, 20000),
     return eta_min + (base_lr * w - eta_min) * (1 + math.cos(math.pi * (step - last_restart) / T)) / 2
 
 
+def _world(group=None):
+    """Number of data-parallel ranks: derived from torch.distributed itself, so that a caller who passes no group
+    while a process group is initialised still gets the GLOBAL dynamic-loss ratio (group None == the WORLD group)."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_world_size(group)
+    return 1
+
+
 class _RegionSums(torch.autograd.Function):
     """sums = (K smooth-L1 numerators | K areas | sum|sr-hr|) in ONE pass over sr, hr (dasr_loss_sums); the
     backward is one elementwise pass (dasr_loss_bwd).  One-hot masks only (region bytes from dasr_mask_compress)."""
@@ -62,15 +70,14 @@ def fused_losses(sr, hr, mask_list, trainable_weight, pixel_weight, dynamic_weig
     h, w = mask_list.shape[2:]
     if H % h or W % w or H // h != W // w:
         return None
-    region = getattr(mask_list, "_dasr_region", None)        # prepared on the device: one-hot by construction
-    if region is None or tuple(region.shape) != (mask_list.shape[0], h, w):
-        region, flag = ops.mask_compress(mask_list.contiguous())
-        if int(flag.item()) != 0:
-            return None
+    from . import graph, prep
+    if not prep.attach_region(mask_list):     # no-op for masks from prep.depth_to_masks / already checked this step
+        return None
+    region = graph.attached_region(mask_list)
     K = mask_list.shape[1]
     sums = _RegionSums.apply(sr, hr, region, K)
     num, den, l1 = sums[:K], sums[K:2 * K].detach(), sums[2 * K]
-    world = torch.distributed.get_world_size(group) if (group is not None and torch.distributed.is_initialized()) else 1
+    world = _world(group)
     l_pix = pixel_weight * l1 / sr.numel()
     if world > 1:
         gden, gnum = den.clone(), num.detach().clone()
@@ -99,7 +106,7 @@ class DynamicMaskLoss(torch.nn.Module):
 
     def forward(self, sr, hr, mask_list, group=None):
         K = mask_list.shape[1]
-        assert K == self.trainable_weight.numel(), "The number of trainable parameters for dynamic loss is not enought."
+        assert K == self.trainable_weight.numel(), "dynamic loss: %d trainable region weights but %d mask channels" % (self.trainable_weight.numel(), K)
         sm = F.softmax(self.trainable_weight, dim=0)
         diff = sr - hr
         nums, dens = [], []
@@ -108,9 +115,7 @@ class DynamicMaskLoss(torch.nn.Module):
             nums.append(F.smooth_l1_loss(m * diff, torch.zeros_like(diff), reduction="none").sum())
             dens.append(3.0 * m.sum())
         num, den = torch.stack(nums), torch.stack(dens)
-        world = 1
-        if group is not None and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(group)
+        world = _world(group)
         if world > 1:
             gden = den.detach().clone()
             gnum = num.detach().clone()
@@ -134,9 +139,10 @@ class Trainer:
                  dynamic_weight=10.0, group=None, T_period=(20000,) * 4, restarts=(20000, 40000, 60000),
                  restart_weights=(1, 1, 1), eta_min=1e-7):
         self.net = net
+        if group is None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            group = torch.distributed.group.WORLD
         self.group = group
-        self.world = torch.distributed.get_world_size(group) if (group is not None or (
-            torch.distributed.is_available() and torch.distributed.is_initialized())) else 1
+        self.world = _world(group)
         device = next(net.parameters()).device
         self.dynamic_loss = DynamicMaskLoss(num_regions, dynamic_weight).to(device)
         self.l_pix_w = pixel_weight
@@ -177,6 +183,9 @@ class Trainer:
     def optimize_parameters(self, lq, gt, depth, masks):
         self.update_learning_rate()
         self.optimizer.zero_grad(set_to_none=True)
+        if masks.is_cuda:
+            from . import prep
+            prep.attach_region(masks)          # before the step's work is queued; free for prep.depth_to_masks output
         sr = self.net(lq, depth, masks)
         grp = self.group if self.world > 1 else None
         fused = fused_losses(sr, gt, masks, self.dynamic_loss.trainable_weight, self.l_pix_w,

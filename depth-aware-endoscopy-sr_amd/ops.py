@@ -63,6 +63,15 @@ def resize_nearest_nchw(x, H, W):
     return out
 
 
+def resize_nearest_u8(region, H, W):
+    B, h, w = region.shape
+    if (h, w) == (H, W):
+        return region
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=region.device)
+    _call("dasr_resize_nearest_u8", _lib.ptr(region, dtype=torch.uint8), _lib.ptr(out, dtype=torch.uint8), B, h, w, H, W)
+    return out
+
+
 def add(a, b):
     out = torch.empty_like(a)
     _call("dasr_add", _p(a), _p(b), _p(out), a.numel())

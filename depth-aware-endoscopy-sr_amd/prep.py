@@ -34,6 +34,7 @@ def depth_to_masks(depth, num_masks=10, fixed_range=False):
     edges = fixed_range_edges(num_masks, depth.device) if fixed_range else None
     planes, region = ops.depth_to_masks(depth, num_masks, edges, want_planes=True)
     planes._dasr_region = region
+    planes._dasr_version = planes._version     # the shortcut is dropped if the tensor is edited in place afterwards
     return planes
 
 
@@ -41,3 +42,21 @@ def depth_to_region(depth, num_masks=10, fixed_range=False):
     """Region bytes only (``[B,h,w]`` uint8; ``num_masks`` = "no bin")."""
     edges = fixed_range_edges(num_masks, depth.device) if fixed_range else None
     return ops.depth_to_masks(depth, num_masks, edges, want_planes=False)[1]
+
+
+def attach_region(masks):
+    """Give a mask tensor that did NOT come from ``depth_to_masks`` (e.g. the reference's CPU dataloader output moved to
+    the GPU) its region bytes, so that the generator and the fused loss take the one-hot kernels without ever reading
+    a flag back mid-step.  Costs one compression pass and ONE 4-byte read-back, here, before any of the step's work is
+    queued.  Returns True when the masks are one-hot (region attached), False for soft / overlapping masks."""
+    from . import graph
+    if graph.attached_region(masks) is not None:
+        return True
+    if not masks.is_cuda or masks.dtype != torch.float32 or not masks.is_contiguous():
+        return False
+    region, flag = ops.mask_compress(masks)
+    if int(flag.item()) != 0:
+        return False
+    masks._dasr_region = region
+    masks._dasr_version = masks._version
+    return True

@@ -61,6 +61,10 @@ int dasr_clamp_to_nchw_bwd(const float* dout_nchw, const float* y_nhwc, float* d
                            float lo, float hi, void* stream);
 /* F.interpolate(mode='nearest') of an NCHW tensor (normalization.py:58-59). */
 int dasr_resize_nearest_nchw(const float* src, float* dst, int BC, int h, int w, int H, int W, void* stream);
+/* The same index map applied to the region bytes [B,h,w] -> [B,H,W] of one-hot masks (nearest resize of the K planes
+ * == one-hot of the resized region byte): SEAN's mask resize (normalization.py:59) without touching the planes. */
+int dasr_resize_nearest_u8(const unsigned char* src, unsigned char* dst, int B, int h, int w, int H, int W,
+                           void* stream);
 
 /* ---- weights -------------------------------------------------------------------------------
  * torch.nn.utils.weight_norm, dim 0 (sftmd_arch.py:741,851 and every wn(...) site):

@@ -77,6 +77,32 @@ TRAIN_CASE = dict(name="train", scale=8, which=[0, 1], L=32, nb=4, B=2, H=8, W=1
                          "upscale3.0.weight_g", "depth-residual1.conv1.0.bias"])
 
 
+# BASELINE.json configs[1]'s network on one frame: the reference is run in float64 once (oracle/make_golden.py,
+# section 10) and only digests are kept
+FULL_X8_CASE = dict(name="full_x8", scale=8, which=list(range(14)), L=256, nb=16, B=1, H=128, W=160)
+FULL_DIGEST_STRIDE = 499
+OUT_SAMPLE_STRIDE = 193
+
+
+def depth_mask_cases():
+    """RNG-free depth maps for the getDepthMask fixtures: name -> (depth [1,h,w] float32, depthFixedRange, K)."""
+    cases = {}
+    for i, (h, w, K) in enumerate(((16, 20, 10), (33, 47, 10), (24, 31, 7), (19, 23, 16))):
+        d = synth.closed_form_frame(i, h, w, 1)[2]                      # smooth field in (0.01, 10): data range
+        cases["smooth%d_K%d" % (i, K)] = (d, False, K)
+        cases["smooth%d_K%d_fixed" % (i, K)] = (d / 10.0, True, K)      # inside [0, 1): fixed range
+    u = synth.hash_uniform(2 * 19 * 23, "depthmask.u").reshape(2, 19, 23).to(torch.float32)
+    cases["noise_data"] = (u[:1] * 9.99 + 0.01, False, 10)
+    cases["noise_outside_fixed"] = (u[1:] * 1.4 - 0.2, True, 10)        # values below 0 and above 1: no bin
+    cases["constant"] = (torch.full((1, 8, 12), 3.25), False, 10)       # interval 0: every bin empty
+    cases["constant_fixed"] = (torch.full((1, 8, 12), 0.25), True, 10)
+    edges = ((torch.arange(24 * 40, dtype=torch.float32) % 11) / 10.0).reshape(1, 24, 40)
+    cases["edges_data"] = (edges, False, 10)                            # pixels exactly on bin edges and on the max
+    cases["edges_fixed"] = (edges, True, 10)
+    cases["edges_fixed_K7"] = (edges, True, 7)
+    return cases
+
+
 def make_case_cfg(case):
     return dict(which_ResBlk_depth=list(case["which"]), in_nc=3, out_nc=3, nf=64, nb=case["nb"], scale=case["scale"],
                 depth_latent_ch=case["L"], depthRangeNum=10, use_trainable_params=True, norm_gamma=0.1,
@@ -88,13 +114,13 @@ DIGEST_FULL_MAX = 2048
 DIGEST_STRIDE = 97
 
 
-def grad_digest(g):
+def grad_digest(g, stride=DIGEST_STRIDE):
     """Small tensors in full; large ones as [L2 norm, sum, strided sample...]."""
     g = torch.as_tensor(g).detach().reshape(-1).to(torch.float64)
     if g.numel() <= DIGEST_FULL_MAX:
         return g.numpy()
     head = torch.stack([g.norm(), g.sum()])
-    return torch.cat([head, g[::DIGEST_STRIDE]]).numpy()
+    return torch.cat([head, g[::stride]]).numpy()
 
 
 def digest_close(got, want, rtol, atol):

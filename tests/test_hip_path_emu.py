@@ -42,11 +42,8 @@ def test_encoder_geometry(emu):
 
 @pytest.mark.parametrize("case", DEPTHNET_CASES, ids=[c["name"] for c in DEPTHNET_CASES])
 def test_depthnet(emu, case):
-    # whole-net fp32 gradients move by up to ~1 % when a single ReLU / clamp decision flips (a 1e-7 effect in the
-    # forward); the smooth cases sit at 1e-6, flip-prone ones at 1e-3..3e-2
-    tol = 0.2 if case["name"].endswith("odd") else 1e-2
-    r = pc.check_depthnet_case(case, "cpu", lin_tol=tol, loss_tol=0.3, lin64_tol=2e-3)
-    print(case["name"], r)
+    # gates per case in parity_checks.DEPTHNET_GATES: gradients against the reference's float64 run, <= 10x measured
+    print(case["name"], pc.check_depthnet_case(case, "cpu"))
 
 
 def test_soft_masks_whole_net(emu):
@@ -79,3 +76,23 @@ def test_other_region_counts(emu):
 
 def test_conv_fwd_stats(emu):
     print(pc.check_conv_fwd_stats("cpu"))
+
+
+def test_train_step_matches_reference(emu):
+    print(pc.check_train_step("cpu"))
+
+
+def test_define_g(emu):
+    print(pc.check_define_g("cpu"))
+
+
+def test_depth_mask_golden(emu):
+    print(pc.check_depth_mask_golden("cpu"))
+
+
+def test_replica_protocol(emu):
+    print(pc.check_replica_protocol("cpu"))
+
+
+def test_region_shortcut_invalidation(emu):
+    print(pc.check_region_shortcut_invalidation("cpu"))
