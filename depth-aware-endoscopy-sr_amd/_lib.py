@@ -29,6 +29,7 @@ _CTYPES = {
     "const void*": ctypes.c_void_p, "int": ctypes.c_int, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
     "const char*": ctypes.c_char_p, "const unsigned char*": ctypes.c_void_p, "unsigned char*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p,
+    "const unsigned short*": ctypes.c_void_p, "unsigned short*": ctypes.c_void_p,      # bf16 bits
 }
 
 

@@ -11,6 +11,7 @@
 // so every MFMA runs at 27/32 (fwd, wgrad) or 27/28 (dgrad) useful width.  dy has 3 channels, so its
 // haloed tile is tiny (14 KB) and consecutive lanes read it at a 3-float stride (conflict-free: gcd(3,32)=1).
 #include "dasr_common.h"
+#include "bf16.h"
 #include "conv_kernels.h"
 
 #define C9_TH 8           // tile rows
@@ -20,19 +21,23 @@
 #define C9_PST 28         // P row stride (27 used)
 #define C9_DYW ((C9_TQ + 8) * 3 + 8)   // dy tile row stride in floats: 72 px * 3 ch + pad
 
+// TX (template parameter of the kernels) = storage type of the Cin-channel activation (x, dx, mask_src): float, or
+// bf16_t on the mixed-precision path.  The 3-channel image side (y, dy), the kernel and the arithmetic (exact-fp32
+// MFMA) are fp32 in both: this convolution produces the network's output.
 struct Conv9Args {
-    const float* x;      // fwd/wgrad: [B,H,W,Cin] ; dgrad: unused
+    const void* x;       // fwd/wgrad: [B,H,W,Cin] (TX) ; dgrad: unused
     const float* w;      // HWIO [9][9][Cin][Cout]
     const float* bias;   // fwd
     const float* dy;     // dgrad/wgrad: [B,H,W,Cout]
-    float* out;          // fwd: y [B,H,W,Cout]; dgrad: dx [B,H,W,Cin]; wgrad: slabs
+    void* out;           // fwd: y [B,H,W,Cout] (float); dgrad: dx [B,H,W,Cin] (TX); wgrad: slabs (float)
     int B, H, W, Cin, Cout;
     int accumulate, P, ntiles;
-    const float* mask_src;   // dgrad: see ConvMfmaArgs::mask_src (conv_mfma.hip)
+    const void* mask_src;    // dgrad: see ConvMfmaArgs::mask_src (conv_mfma.hip) (TX)
     int mask_act, unps_r;
 };
 
 // ------------------------------------------------------------------------------------------ forward
+template <typename TX>
 __global__ void __launch_bounds__(256) k_conv9x9_fwd_mfma(Conv9Args a) {
     DASR_DYN_SMEM(smem);
     float* sIn = (float*)smem;                                    // [16][64][CKP]  (later: P [8][64][PST])
@@ -62,7 +67,7 @@ __global__ void __launch_bounds__(256) k_conv9x9_fwd_mfma(Conv9Args a) {
             const int gy = y0 - 4 + pix / C9_TQ, gx = x0 - 4 + pix % C9_TQ;
             vin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                vin[u] = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
+                vin[u] = ld4((const TX*)a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
         }
 #pragma unroll
         for (int u = 0; u < NW9; ++u) {
@@ -125,7 +130,7 @@ __global__ void __launch_bounds__(256) k_conv9x9_fwd_mfma(Conv9Args a) {
         float v = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
         for (int kw = 0; kw < 9; ++kw) v += sP[(r * C9_TQ + ox + kw) * C9_PST + kw * a.Cout + co];
-        a.out[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co] = v;
+        ((float*)a.out)[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co] = v;
     }
 }
 
@@ -155,7 +160,7 @@ __device__ __forceinline__ void c9_store_dy(float* sDy, const float (&v)[C9_NDY]
     }
 }
 
-template <bool UNMASK>
+template <bool UNMASK, typename TX>
 __global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
     DASR_DYN_SMEM(smem);
     float* sDy = (float*)smem;                       // [16][DYW]
@@ -217,15 +222,15 @@ __global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
             size_t o = (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + n0 + li;
             float v = acc[t][g];
             if (UNMASK) {
-                v *= dasr_act_grad_from_out(a.mask_src[o], a.mask_act);
+                v *= dasr_act_grad_from_out(ld1((const TX*)a.mask_src + o), a.mask_act);
                 if (a.unps_r > 1) {
                     const int ur = a.unps_r;
                     o = ((((size_t)b * (a.H / ur) + gy / ur) * (a.W / ur) + gx / ur) * a.Cin + n0 + li) * (ur * ur) +
                         (gy % ur) * ur + (gx % ur);
                 }
             }
-            if (a.accumulate) v += a.out[o];
-            a.out[o] = v;
+            if (a.accumulate) v += ld1((const TX*)a.out + o);
+            st1((TX*)a.out + o, v);
         }
     }
 }
@@ -234,6 +239,7 @@ __global__ void __launch_bounds__(256) k_conv9x9_dgrad_mfma(Conv9Args a) {
 // Workgroup walks a strip of 8 x 64 pixel tiles; wave w owns tile rows 2w, 2w+1 and keeps nine
 // [32 ci x 32 n'] accumulators (one per kh).  Each wave writes its own slab [9][32][32];
 // k_conv9_wgrad_reduce sums slabs in a fixed order and un-folds n' = (8-kw)*3 + co.
+template <typename TX>
 __global__ void __launch_bounds__(256, 2) k_conv9x9_wgrad_mfma(Conv9Args a) {
     DASR_DYN_SMEM(smem);
     float* sX = (float*)smem;                         // [8][64][32]
@@ -259,7 +265,7 @@ __global__ void __launch_bounds__(256, 2) k_conv9x9_wgrad_mfma(Conv9Args a) {
                 const int gy = y0 + pix / C9_TQ, gx = x0 + pix % C9_TQ;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (gy < a.H && gx < a.W)
-                    v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
+                    v = ld4((const TX*)a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
                 return v;
             };
             auto stx = [&](int u, float4 v) {
@@ -294,7 +300,7 @@ __global__ void __launch_bounds__(256, 2) k_conv9x9_wgrad_mfma(Conv9Args a) {
             for (int kh = 0; kh < 9; ++kh) acc[kh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv[kh], acc[kh], 0, 0, 0);
         }
     }
-    float* slab = a.out + ((size_t)(blockIdx.y * 4 + wv) * gridDim.x + blockIdx.x) * (9 * 32 * 32);
+    float* slab = (float*)a.out + ((size_t)(blockIdx.y * 4 + wv) * gridDim.x + blockIdx.x) * (9 * 32 * 32);
 #pragma unroll
     for (int kh = 0; kh < 9; ++kh)
 #pragma unroll
@@ -326,26 +332,41 @@ bool conv9_mfma_supported(const ConvGeom& g) {
     return g.KH == 9 && g.KW == 9 && g.stride == 1 && g.pad == 4 && !g.transposed && (g.Cin % 32) == 0 &&
            g.Cout >= 1 && g.Cout <= 3 && g.H == g.Ho && g.W == g.Wo;
 }
-int conv9_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* stream) {
+template <typename TX>
+static int conv9_fwd_impl(const ConvGeom& g, const TX* x, const float* w, const float* bias, float* y, void* stream) {
     Conv9Args a{x, w, bias, nullptr, y, g.B, g.H, g.W, g.Cin, g.Cout, 0, 0, 0, nullptr, 0, 1};
     int TWO = C9_TQ - 8;
     int tiles = ((g.W + TWO - 1) / TWO) * ((g.H + C9_TH - 1) / C9_TH);
     size_t lds = sizeof(float) * (size_t)((C9_TH + 8) * C9_TQ * C9_CKP + 9 * 32 * C9_CKP);
-    DASR_LAUNCH(k_conv9x9_fwd_mfma, dim3(tiles, g.B), dim3(256), lds, stream, a);
+    DASR_LAUNCH((k_conv9x9_fwd_mfma<TX>), dim3(tiles, g.B), dim3(256), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
 }
-int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate,
-                     const float* mask_src, int mask_act, int unps_r, void* stream) {
+int conv9_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* stream) {
+    return conv9_fwd_impl<float>(g, x, w, bias, y, stream);
+}
+int conv9_mfma_fwd_bf16(const ConvGeom& g, const bf16_t* x, const float* w, const float* bias, float* y, void* stream) {
+    return conv9_fwd_impl<bf16_t>(g, x, w, bias, y, stream);
+}
+template <typename TX>
+static int conv9_dgrad_impl(const ConvGeom& g, const float* dconv, const float* w, TX* dx, int accumulate,
+                            const TX* mask_src, int mask_act, int unps_r, void* stream) {
     Conv9Args a{nullptr, w, nullptr, dconv, dx, g.B, g.H, g.W, g.Cin, g.Cout, accumulate, 0, 0,
                 mask_src, mask_act, unps_r < 1 ? 1 : unps_r};
     int tiles = ((g.W + C9_TQ - 1) / C9_TQ) * ((g.H + C9_TH - 1) / C9_TH);
     size_t lds = sizeof(float) * (size_t)((C9_TH + 8) * C9_DYW + 9 * 28 * 32);
     if (mask_src) {
-        DASR_LAUNCH((k_conv9x9_dgrad_mfma<true>), dim3(tiles, g.B, g.Cin / 32), dim3(256), lds, stream, a);
+        DASR_LAUNCH((k_conv9x9_dgrad_mfma<true, TX>), dim3(tiles, g.B, g.Cin / 32), dim3(256), lds, stream, a);
     } else {
-        DASR_LAUNCH((k_conv9x9_dgrad_mfma<false>), dim3(tiles, g.B, g.Cin / 32), dim3(256), lds, stream, a);
+        DASR_LAUNCH((k_conv9x9_dgrad_mfma<false, TX>), dim3(tiles, g.B, g.Cin / 32), dim3(256), lds, stream, a);
     }
     DASR_RETURN_LAUNCH_STATUS();
+}
+int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate,
+                     const float* mask_src, int mask_act, int unps_r, void* stream) {
+    return conv9_dgrad_impl<float>(g, dconv, w, dx, accumulate, mask_src, mask_act, unps_r, stream);
+}
+int conv9_mfma_dgrad_bf16(const ConvGeom& g, const float* dconv, const float* w, bf16_t* dx, int accumulate, void* stream) {
+    return conv9_dgrad_impl<bf16_t>(g, dconv, w, dx, accumulate, nullptr, 0, 1, stream);
 }
 static void conv9_wgrad_plan(const ConvGeom& g, int& ntiles, int& P) {
     ntiles = g.B * ((g.H + C9_TH - 1) / C9_TH) * ((g.W + C9_TQ - 1) / C9_TQ);
@@ -358,12 +379,13 @@ size_t conv9_mfma_wgrad_workspace(const ConvGeom& g) {
     conv9_wgrad_plan(g, ntiles, P);
     return sizeof(float) * (size_t)P * 4 * (g.Cin / 32) * 9 * 32 * 32;
 }
-int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream) {
+template <typename TX>
+static int conv9_wgrad_impl(const ConvGeom& g, const TX* x, const float* dconv, float* dw, void* workspace, void* stream) {
     int ntiles, P;
     conv9_wgrad_plan(g, ntiles, P);
-    Conv9Args a{x, nullptr, nullptr, dconv, (float*)workspace, g.B, g.H, g.W, g.Cin, g.Cout, 0, P, ntiles, nullptr, 0, 1};
+    Conv9Args a{x, nullptr, nullptr, dconv, workspace, g.B, g.H, g.W, g.Cin, g.Cout, 0, P, ntiles, nullptr, 0, 1};
     size_t lds = sizeof(float) * (size_t)(C9_TH * C9_TQ * 32 + (C9_TH + 8) * C9_DYW);
-    DASR_LAUNCH(k_conv9x9_wgrad_mfma, dim3(g.Cin / 32, P), dim3(256), lds, stream, a);
+    DASR_LAUNCH((k_conv9x9_wgrad_mfma<TX>), dim3(g.Cin / 32, P), dim3(256), lds, stream, a);
     int n = 81 * g.Cin * g.Cout;
     hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * n, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
@@ -371,4 +393,10 @@ int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, floa
     DASR_LAUNCH(k_conv9_wgrad_reduce, dim3(dasr_cdiv(n, 256), ysplit), dim3(256), 0, stream, (const float*)workspace, dw,
                 g.Cin, g.Cout, nslabs, g.Cin / 32, (nslabs + ysplit - 1) / ysplit);
     DASR_RETURN_LAUNCH_STATUS();
+}
+int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream) {
+    return conv9_wgrad_impl<float>(g, x, dconv, dw, workspace, stream);
+}
+int conv9_mfma_wgrad_bf16(const ConvGeom& g, const bf16_t* x, const float* dconv, float* dw, void* workspace, void* stream) {
+    return conv9_wgrad_impl<bf16_t>(g, x, dconv, dw, workspace, stream);
 }

@@ -160,3 +160,105 @@ extern "C" int dasr_conv2d_dgrad_act(const float* dconv, const float* w, const f
     if (conv_mfma_dgrad_supported(g)) return conv_mfma_dgrad(g, dconv, w, dprev, 0, x_act, act, ps_r, stream);
     return conv9_mfma_dgrad(g, dconv, w, dprev, 0, x_act, act, ps_r, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Mixed-precision entry points (bf16 activations; BASELINE.json configs[2..3]).  Three layer kinds exist on that path,
+// told apart by the geometry; anything else returns DASR_E_UNSUPPORTED (the bf16 path has no generic fallback):
+//   trunk   3x3 / stride 1 / pad 1, Cin % 32 == 0, Cout % 32 == 0   x bf16, w packed bf16, y / residual bf16
+//   mask    3x3, Cin == 1 (SEAN.mlp_mask on the fp32 depth map)     x f32,  w packed f32,  y bf16
+//   output  9x9 / pad 4, Cout <= 3 (conv_output)                    x bf16, w packed f32,  y f32
+// bias, dw, dbias are always fp32.
+static int bf16_kind(const ConvGeom& g) {
+    if (conv_bf16_supported(g)) return 1;
+    if (conv_c1_supported(g)) return 2;
+    if (conv9_mfma_supported(g)) return 3;
+    return 0;
+}
+extern "C" int dasr_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, const unsigned short* residual,
+                                    void* y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                    int stride, int pad, int transposed, int act, int ps_r, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(w); DASR_CHECK_PTR(y);
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
+    if (ps_r < 1) ps_r = 1;
+    if (ps_r > 1 && (Cout % (ps_r * ps_r)) != 0) return DASR_E_SHAPE;
+    switch (bf16_kind(g)) {
+        case 1:
+            return conv_bf16_fwd(g, (const bf16_t*)x, (const bf16_t*)w, bias, (const bf16_t*)residual, (bf16_t*)y, act, ps_r,
+                                 stream);
+        case 2:
+            if (ps_r != 1 || residual) return DASR_E_UNSUPPORTED;
+            return conv_c1_fwd_bf16(g, (const float*)x, (const float*)w, bias, (bf16_t*)y, act, stream);
+        case 3:
+            if (ps_r != 1 || residual || act != DASR_ACT_NONE) return DASR_E_UNSUPPORTED;
+            return conv9_mfma_fwd_bf16(g, (const bf16_t*)x, (const float*)w, bias, (float*)y, stream);
+    }
+    return DASR_E_UNSUPPORTED;
+}
+extern "C" int dasr_conv2d_epilogue_bwd_bf16(const unsigned short* dy, const unsigned short* y, unsigned short* dconv,
+                                             int B, int Ho, int Wo, int Cout, int act, int ps_r, void* stream) {
+    DASR_CHECK_PTR(dy); DASR_CHECK_PTR(y); DASR_CHECK_PTR(dconv);
+    DASR_CHECK_SHAPE(B > 0 && Ho > 0 && Wo > 0 && Cout > 0);
+    if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
+    if (ps_r < 1) ps_r = 1;
+    if (ps_r > 1 && (Cout % (ps_r * ps_r)) != 0) return DASR_E_SHAPE;
+    ConvGeom g{B, Ho, Wo, 1, Ho, Wo, Cout, 1, 1, 1, 0, 0};
+    return conv_epilogue_bwd_bf16(g, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dconv, act, ps_r, stream);
+}
+// trunk: dconv bf16, w packed bf16, dx bf16;  output conv: dconv f32, w packed f32, dx bf16
+extern "C" int dasr_conv2d_dgrad_bf16(const void* dconv, const void* w, unsigned short* dx, int accumulate, int B, int H,
+                                      int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                                      int transposed, void* stream) {
+    DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(w); DASR_CHECK_PTR(dx);
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (conv_bf16_dgrad_supported(g))
+        return conv_bf16_dgrad(g, (const bf16_t*)dconv, (const bf16_t*)w, (bf16_t*)dx, accumulate, stream);
+    if (conv9_mfma_supported(g))
+        return conv9_mfma_dgrad_bf16(g, (const float*)dconv, (const float*)w, (bf16_t*)dx, accumulate, stream);
+    return DASR_E_UNSUPPORTED;
+}
+extern "C" size_t dasr_conv2d_wgrad_workspace_bf16(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                                   int stride, int pad, int transposed) {
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    if (check_geom(g) != DASR_OK) return 0;
+    if (conv_bf16_wgrad_supported(g)) return conv_bf16_wgrad_workspace(g);
+    if (conv9_mfma_supported(g)) return conv9_mfma_wgrad_workspace(g);
+    return 0;
+}
+// trunk: x bf16, dconv bf16;  output conv: x bf16, dconv f32.  dw (plain HWIO) and dbias are fp32.
+extern "C" int dasr_conv2d_wgrad_bf16(const unsigned short* x, const void* dconv, float* dw, float* dbias, void* workspace,
+                                      size_t workspace_bytes, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
+                                      int KW, int stride, int pad, int transposed, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(dw); DASR_CHECK_PTR(workspace);
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (conv_bf16_wgrad_supported(g)) {
+        if (workspace_bytes < conv_bf16_wgrad_workspace(g)) return DASR_E_WORKSPACE;
+        return conv_bf16_wgrad(g, (const bf16_t*)x, (const bf16_t*)dconv, dw, dbias, workspace, stream);
+    }
+    if (conv9_mfma_supported(g)) {
+        if (workspace_bytes < conv9_mfma_wgrad_workspace(g)) return DASR_E_WORKSPACE;
+        rc = conv9_mfma_wgrad_bf16(g, (const bf16_t*)x, (const float*)dconv, dw, workspace, stream);
+        if (rc) return rc;
+        if (dbias) rc = conv_colsum((const float*)dconv, dbias, (size_t)B * Ho * Wo, Cout, stream);
+        return rc;
+    }
+    return DASR_E_UNSUPPORTED;
+}
+// SEAN.mlp_mask: weight / bias gradient with the ReLU backward fused; x = depth map (f32), dy / y bf16
+extern "C" int dasr_conv2d_wgrad_act_bf16(const float* x, const unsigned short* dy, const unsigned short* y, float* dw,
+                                          float* dbias, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
+                                          int KW, int stride, int pad, int transposed, int act, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(dy); DASR_CHECK_PTR(y); DASR_CHECK_PTR(dw);
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
+    if (!conv_c1_supported(g)) return DASR_E_UNSUPPORTED;
+    return conv_c1_wgrad_bf16(g, x, (const bf16_t*)dy, (const bf16_t*)y, act, dw, dbias, stream);
+}

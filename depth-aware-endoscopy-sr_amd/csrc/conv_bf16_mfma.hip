@@ -1,0 +1,479 @@
+// conv_bf16_mfma.hip — the trunk's 3x3 / stride 1 / pad 1 convolutions with bf16 activations and kernels on the bf16
+// matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate: 16x the rate of the exact-fp32 MFMA of conv_mfma.hip), for
+// BASELINE.json configs[2..3].  NHWC bf16 x packed bf16 kernels (dasr_weight_pack_fwd_bf16: HWIO then per-tap transpose).
+//
+//   forward : out[p, co]  = sum_{tap, ci} in[p + off(tap), ci] * W[tap][ci][co]       M = pixels, N = co, K = 9*Cin
+//   dgrad   : the same kernel run on dconv with the taps flipped and ci/co swapped      (WMODE = 1)
+//   wgrad   : dW[tap][ci][co] = sum_p in[p + off(tap), ci] * dconv[p, co]               M = ci,  N = co, K = pixels
+//
+// Forward / dgrad.  Workgroup = 4 waves, output tile = 8 rows x 32 columns of pixels x 32*NT output channels; wave w owns
+// rows 2w, 2w+1.  K loop over 32-channel chunks: the 10 x 34 halo tile and the 9 x (32*NT) x 32 kernel slice are staged in
+// LDS with an 80-byte pixel / channel stride (5 x 16 B: the 16 lanes of every ds_read_b128 lane group hit 16 distinct
+// 4-bank slots).  One ds_read_b128 IS one MFMA operand: lane (i, h) holds channels 16q+8h .. +7 of pixel i (A) or of
+// output channel i (B).  Software pipeline as in conv_mfma.hip: chunk c+1 is fetched into registers before the MFMAs of
+// chunk c and written to LDS after them.
+// Epilogue.  The D fragment has the output channel on the lane and 16 pixels in registers; stored as it stands that is
+// 2 bytes per lane per store.  Instead every wave passes its rows through its own slice of LDS ([pixel][co] fp32, the
+// operand buffers are dead by then) and reads them back with 8 consecutive channels of one pixel per lane: residual /
+// accumulate operands are fetched and the result stored 16 bytes per lane, 8 lanes (NT=2) per 128-byte pixel.  The
+// PixelShuffle(2) store gathers its 8 channels at stride 4 from the same LDS image.
+//
+// Weight gradient.  K = pixels, 16 per MFMA: the operand a lane needs is 8 CONSECUTIVE PIXELS of one channel, i.e. the
+// transpose of NHWC.  The tiles are staged as they come ([pixel][channel], coalesced) and read with ds_read_b64_tr_b16,
+// gfx950's transposing LDS read (cdna_hip_programming.md T10): two of them per operand.  Pixel strides of 64 or 192
+// bytes make those reads conflict-free.  Accumulators stay resident over a strip of tiles; slabs + the fixed-order
+// reduction of conv_mfma.hip (k_wgrad_reduce) finish the sum in fp32.
+#include "bf16.h"
+#include "conv_kernels.h"
+
+#define CB_TW 32
+#define CB_CK 32
+#define CB_CKP 40
+#define CB_HALO_W (CB_TW + 2)
+#define CB_MTW 2
+#define CB_TH (4 * CB_MTW)
+#define CB_HALO_H (CB_TH + 2)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvBf16Args {
+    const bf16_t* x;         // [B,H,W,Cin]
+    const bf16_t* w;         // packed bf16 kernel of the FORWARD conv: [2][9][..][..] (HWIO, then [tap][co][ci])
+    const float* bias;       // [Cout] or null (fp32)
+    const bf16_t* residual;  // [B,H,W,Cout] or null
+    bf16_t* y;
+    int B, H, W, Cin, Cout;
+    int act, ps_r, accumulate;
+};
+
+template <int NT, int WMODE>
+__global__ void __launch_bounds__(256, 2) k_conv3x3_bf16(ConvBf16Args a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int NTILE = 32 * NT;
+    bf16_t* sIn = (bf16_t*)smem;                                  // [HALO_H*HALO_W][CKP]
+    bf16_t* sW = sIn + CB_HALO_H * CB_HALO_W * CB_CKP;            // [9][NTILE][CKP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    // XCD-aware block order: the N-slices of one pixel tile get workgroup ids 8 apart (same XCD, back to back)
+    const int tiles_x = (a.W + CB_TW - 1) / CB_TW, tiles_y = (a.H + CB_TH - 1) / CB_TH;
+    const int nsl = a.Cout / NTILE, G = tiles_x * tiles_y * a.B;
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int gt = (kq / nsl) * 8 + xcd;
+    if (gt >= G) return;
+    const int tile = gt % (tiles_x * tiles_y);
+    const int x0 = (tile % tiles_x) * CB_TW, y0 = (tile / tiles_x) * CB_TH;
+    const int b = gt / (tiles_x * tiles_y), n0 = (kq % nsl) * NTILE;
+
+    f32x16 acc[CB_MTW][NT];
+#pragma unroll
+    for (int m = 0; m < CB_MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    constexpr int NINP = CB_HALO_H * CB_HALO_W * 4;               // 16-byte pieces of the halo tile (4 per pixel)
+    constexpr int NWTP = 9 * NTILE * 4;
+    constexpr int NIN = (NINP + 255) / 256, NWT = (NWTP + 255) / 256;
+    u32x4 pin[NIN], pwt[NWT];
+    const bf16_t* wsrc = WMODE == 0 ? a.w + (size_t)9 * a.Cin * a.Cout : a.w;
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            const int idx = tid + 256 * u;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < NINP) {
+                const int pix = idx >> 2, q4 = idx & 3;
+                const int gy = y0 + pix / CB_HALO_W - 1, gx = x0 + pix % CB_HALO_W - 1;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *(const u32x4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 8 * q4);
+            }
+            pin[u] = v;
+        }
+        // kernel slice as [tap][n][k], k contiguous in both modes:
+        //   forward: second half of the packed kernel, [tap][co][ci];  dgrad: first half (HWIO = [tap][n = ci_f][k = co_f]),
+        //   taps flipped
+#pragma unroll
+        for (int u = 0; u < NWT; ++u) {
+            const int idx = tid + 256 * u;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < NWTP) {
+                const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
+                const int tsrc = WMODE == 0 ? tap : 8 - tap;
+                v = *(const u32x4*)(wsrc + ((size_t)tsrc * a.Cout + n0 + nl) * a.Cin + c0 + 8 * q4);
+            }
+            pwt[u] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < NINP) *(u32x4*)(sIn + (idx >> 2) * CB_CKP + 8 * (idx & 3)) = pin[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NWT; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < NWTP) {
+                const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
+                *(u32x4*)(sW + (tap * NTILE + nl) * CB_CKP + 8 * q4) = pwt[u];
+            }
+        }
+    };
+    prefetch(0);
+    for (int c0 = 0; c0 < a.Cin; c0 += CB_CK) {
+        __syncthreads();                       // every wave is done reading the previous chunk
+        commit();
+        __syncthreads();
+        if (c0 + CB_CK < a.Cin) prefetch(c0 + CB_CK);
+        // 9 taps x 2 K-steps of 16 channels; the operands of step j+1 are read while the MFMAs of step j run
+        auto ldfrag = [&](int j, bf16x8 (&A)[CB_MTW], bf16x8 (&Bf)[NT]) {
+            const int tap = j >> 1, q = j & 1;
+            const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+            for (int m = 0; m < CB_MTW; ++m)
+                A[m] = *(const bf16x8*)(sIn + ((CB_MTW * wv + m + dy) * CB_HALO_W + li + dx) * CB_CKP + 16 * q + 8 * lh);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                Bf[n] = *(const bf16x8*)(sW + (tap * NTILE + 32 * n + li) * CB_CKP + 16 * q + 8 * lh);
+        };
+        auto mma = [&](const bf16x8 (&A)[CB_MTW], const bf16x8 (&Bf)[NT]) {
+#pragma unroll
+            for (int m = 0; m < CB_MTW; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], Bf[n], acc[m][n], 0, 0, 0);
+        };
+        bf16x8 A0[CB_MTW], B0[NT], A1[CB_MTW], B1[NT];
+        ldfrag(0, A0, B0);
+#pragma unroll
+        for (int j = 0; j < 18; j += 2) {
+            ldfrag(j + 1, A1, B1);
+            mma(A0, B0);
+            if (j + 2 < 18) ldfrag(j + 2, A0, B0);
+            mma(A1, B1);
+        }
+    }
+
+    // ---- epilogue
+    const int ps = a.ps_r, rr = ps * ps;
+    const bool fast = x0 + CB_TW <= a.W && (ps == 1 || (ps == 2 && a.residual == nullptr && !a.accumulate));
+    if (fast) {
+        // per wave: [32 pixels][NTILE + 4] fp32 (the +4 keeps the 16-byte alignment and spreads the rows over the banks)
+        constexpr int EP = NTILE + 4;
+        __syncthreads();                       // every wave is done with the last chunk's operands
+        float* sE = (float*)smem + wv * (32 * EP);
+        const bool is_relu = a.act == DASR_ACT_RELU;
+        const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
+#pragma unroll
+        for (int m = 0; m < CB_MTW; ++m) {
+            const int gy = y0 + CB_MTW * wv + m;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float bv = a.bias ? a.bias[n0 + 32 * n + li] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sE[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * n + li] = acc[m][n][r] + bv;
+            }
+            __syncthreads();
+            if (gy < a.H) {
+                if (ps == 1) {
+                    constexpr int GP = NTILE / 8;                 // 8-channel groups per pixel
+#pragma unroll
+                    for (int u = 0; u < (32 * GP) / 64; ++u) {
+                        const int v = lane + 64 * u, p = v / GP, cg = v % GP;
+                        const float4 lo = *(const float4*)(sE + p * EP + 8 * cg), hi = *(const float4*)(sE + p * EP + 8 * cg + 4);
+                        float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        const size_t idx = (((size_t)b * a.H + gy) * a.W + x0 + p) * a.Cout + n0 + 8 * cg;
+                        if (a.residual) {
+                            const bf16x8 rv = *(const bf16x8*)(a.residual + idx);
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) o[t] += dasr_bf2f(rv[t]);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const float neg = is_relu ? 0.f : o[t] * slope;
+                            o[t] = o[t] > 0.f ? o[t] : neg;
+                        }
+                        if (a.accumulate) {
+                            const bf16x8 av = *(const bf16x8*)(a.y + idx);
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) o[t] += dasr_bf2f(av[t]);
+                        }
+                        bf16x8 ov;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) ov[t] = dasr_f2bf(o[t]);
+                        *(bf16x8*)(a.y + idx) = ov;
+                    }
+                } else {
+                    // PixelShuffle(2): out[b, 2gy+i, 2gx+j, c] = conv[b, gy, gx, 4c + 2i + j]
+                    constexpr int GS = NTILE / 32;                // 8-channel groups per sub-pixel in this N slice
+                    const int Cq = a.Cout / 4;
+#pragma unroll
+                    for (int u = 0; u < (32 * 4 * GS) / 64; ++u) {
+                        const int v = lane + 64 * u;
+                        const int cg = v % GS, j = (v / GS) & 1, p = (v / (2 * GS)) % 32, i = v / (64 * GS);
+                        float o[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) o[t] = sE[p * EP + 4 * (8 * cg + t) + 2 * i + j];
+                        bf16x8 ov;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const float neg = is_relu ? 0.f : o[t] * slope;
+                            ov[t] = dasr_f2bf(o[t] > 0.f ? o[t] : neg);
+                        }
+                        const size_t idx = (((size_t)b * a.H * 2 + 2 * gy + i) * ((size_t)a.W * 2) + 2 * (x0 + p) + j) * Cq +
+                                           n0 / 4 + 8 * cg;
+                        *(bf16x8*)(a.y + idx) = ov;
+                    }
+                }
+            }
+            __syncthreads();                   // the slice is rewritten by the next row
+        }
+        return;
+    }
+    // generic path (ragged last tile column, PixelShuffle(3), PixelShuffle with residual): element by element
+#pragma unroll
+    for (int m = 0; m < CB_MTW; ++m) {
+        const int gy = y0 + CB_MTW * wv + m;
+        if (gy >= a.H) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n0 + 32 * n + li;
+            const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (gx >= a.W) continue;
+                const size_t pidx = (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co;
+                float v = acc[m][n][r] + bv;
+                if (a.residual) v += dasr_bf2f(a.residual[pidx]);
+                v = dasr_act(v, a.act);
+                size_t o = pidx;
+                if (ps > 1) {
+                    const int c = co / rr, i = (co / ps) % ps, j = co % ps;
+                    o = (((size_t)b * a.H * ps + (size_t)gy * ps + i) * ((size_t)a.W * ps) + (size_t)gx * ps + j) *
+                            (a.Cout / rr) + c;
+                }
+                if (a.accumulate) v += dasr_bf2f(a.y[o]);
+                a.y[o] = dasr_f2bf(v);
+            }
+        }
+    }
+}
+
+static size_t conv_bf16_lds(int NT) {
+    const size_t main_b = sizeof(bf16_t) * (size_t)(CB_HALO_H * CB_HALO_W * CB_CKP + 9 * 32 * NT * CB_CKP);
+    const size_t ep_b = sizeof(float) * (size_t)(4 * 32 * (32 * NT + 4));
+    return main_b > ep_b ? main_b : ep_b;
+}
+
+bool conv_bf16_supported(const ConvGeom& g) {
+    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin % CB_CK) == 0 &&
+           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+}
+bool conv_bf16_dgrad_supported(const ConvGeom& g) {
+    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cout % CB_CK) == 0 &&
+           (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+}
+
+template <int WMODE>
+static int launch_conv_bf16(ConvBf16Args& a, void* stream) {
+    const bool nt2 = (a.Cout % 64) == 0;
+    const int tiles = ((a.W + CB_TW - 1) / CB_TW) * ((a.H + CB_TH - 1) / CB_TH);
+    const int G8 = (tiles * a.B + 7) / 8 * 8;                 // pixel tiles, padded to whole rounds over the 8 XCDs
+    const dim3 grid(G8 * (a.Cout / (nt2 ? 64 : 32)));
+    const size_t lds = conv_bf16_lds(nt2 ? 2 : 1);
+    if (nt2) DASR_LAUNCH((k_conv3x3_bf16<2, WMODE>), grid, dim3(256), lds, stream, a);
+    else     DASR_LAUNCH((k_conv3x3_bf16<1, WMODE>), grid, dim3(256), lds, stream, a);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+
+int conv_bf16_fwd(const ConvGeom& g, const bf16_t* x, const bf16_t* w, const float* bias, const bf16_t* residual,
+                  bf16_t* y, int act, int ps_r, void* stream) {
+    ConvBf16Args a{x, w, bias, residual, y, g.B, g.H, g.W, g.Cin, g.Cout, act, ps_r, 0};
+    return launch_conv_bf16<0>(a, stream);
+}
+// dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * W[tap][ci][co]: a 3x3 conv of dconv (channels Cout) to Cin
+int conv_bf16_dgrad(const ConvGeom& g, const bf16_t* dconv, const bf16_t* w, bf16_t* dx, int accumulate, void* stream) {
+    ConvBf16Args a{dconv, w, nullptr, nullptr, dx, g.B, g.H, g.W, g.Cout, g.Cin, DASR_ACT_NONE, 1, accumulate};
+    return launch_conv_bf16<1>(a, stream);
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+#define WB_TW 32
+__host__ __device__ constexpr int wb_th(int MT, int NTW) { return MT * NTW == 4 ? 4 : 8; }
+// LDS pixel stride in bf16 elements: bytes = 64 (mod 128), so that the four pixel rows of a transposed-read block
+// land in four disjoint 64-byte bank ranges
+__host__ __device__ constexpr int wb_stride(int ch) { return ch == 32 ? 32 : ch + 32; }
+
+struct WgradBf16Args {
+    const bf16_t* x;     // [B,H,W,Cin]
+    const bf16_t* dy;    // [B,H,W,Cout]
+    float* slabs;        // [P][9][Cin][Cout]
+    float* bslabs;       // [P][Cout] or null
+    float* zero;         // dw when the reduction will add into it with atomics, else null: zeroed here
+    size_t nzero;
+    int B, H, W, Cin, Cout;
+    int P, ntiles;
+};
+
+template <int MT, int NTW>
+__global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_bf16(WgradBf16Args a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int CIG = 32 * MT, COG = 32 * NTW;
+    constexpr int TH = wb_th(MT, NTW);
+    constexpr int SXP = wb_stride(CIG), SDP = wb_stride(COG);
+    constexpr int G = 4 / (MT * NTW);           // wave groups sharing one (mt, nt) pair, splitting the taps
+    constexpr int NACC = (9 + G - 1) / G;
+    bf16_t* sX = (bf16_t*)smem;                                   // [(TH+2)*(TW+2)][SXP]
+    bf16_t* sD = sX + (TH + 2) * (WB_TW + 2) * SXP;               // [TH*TW][SDP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int pair = wv % (MT * NTW), grp = wv / (MT * NTW);
+    const int mt = pair / NTW, nt = pair % NTW;
+    const int cgroups = a.Cout / COG;
+    const int ci0 = (blockIdx.x / cgroups) * CIG, co0 = (blockIdx.x % cgroups) * COG;
+    const int tiles_x = (a.W + WB_TW - 1) / WB_TW, tiles_y = (a.H + TH - 1) / TH;
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool do_bias = a.bslabs != nullptr && ci0 == 0 && tid < COG;
+    float bsum = 0.f;
+    if (a.zero) {
+        const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
+        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
+    }
+    // transposed-read lane roles: lane 4q+p of its 16-lane group passes the address of pixel row q, channels 4p..4p+3 of the
+    // group's 16 channels; groups 0,1 cover channels 0..15 / 16..31 of pixels 0..7 of the K-step, groups 2,3 pixels 8..15
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    const int xoff = 32 * mt + 16 * tg + 4 * tp, doff = 32 * nt + 16 * tg + 4 * tp;
+
+    for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx * WB_TW, y0 = ty * TH;
+        constexpr int NX = (TH + 2) * (WB_TW + 2) * (CIG / 8), NXI = (NX + 255) / 256;
+        constexpr int ND = TH * WB_TW * (COG / 8), NDI = (ND + 255) / 256;
+        u32x4 vx[NXI], vd[NDI];
+#pragma unroll
+        for (int u = 0; u < NXI; ++u) {
+            const int idx = tid + 256 * u;
+            const int c8 = idx % (CIG / 8), pix = idx / (CIG / 8);
+            const int gy = y0 + pix / (WB_TW + 2) - 1, gx = x0 + pix % (WB_TW + 2) - 1;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < NX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *(const u32x4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 8 * c8);
+            vx[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NDI; ++u) {
+            const int idx = tid + 256 * u;
+            const int c8 = idx % (COG / 8), pix = idx / (COG / 8);
+            const int gy = y0 + pix / WB_TW, gx = x0 + pix % WB_TW;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < ND && gy < a.H && gx < a.W)
+                v = *(const u32x4*)(a.dy + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 8 * c8);
+            vd[u] = v;
+        }
+        __syncthreads();                        // every wave is done with the previous tile
+#pragma unroll
+        for (int u = 0; u < NXI; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < NX) *(u32x4*)(sX + (idx / (CIG / 8)) * SXP + 8 * (idx % (CIG / 8))) = vx[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NDI; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < ND) *(u32x4*)(sD + (idx / (COG / 8)) * SDP + 8 * (idx % (COG / 8))) = vd[u];
+        }
+        __syncthreads();
+        if (do_bias) {                          // bias gradient: column sums of the staged dy tile
+#pragma unroll 8
+            for (int px = 0; px < TH * WB_TW; ++px) bsum += dasr_bf2f(sD[px * SDP + tid]);
+        }
+        // K-step s = 16 consecutive pixels of one tile row.  EXEC is all ones here (the tile loop and the tap split are
+        // wave-uniform), as ds_read_b64_tr_b16 requires.
+        constexpr int NS = TH * (WB_TW / 16);
+#pragma unroll 2
+        for (int s = 0; s < NS; ++s) {
+            const int py = s / (WB_TW / 16), px0 = 16 * (s % (WB_TW / 16)) + 8 * lh + tq;
+            const bf16_t* dp = sD + (py * WB_TW + px0) * SDP + doff;
+            const bf16x4 b0 = lds_read_tr16(dp), b1 = lds_read_tr16(dp + 4 * SDP);
+            bf16x8 bv;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { bv[t] = b0[t]; bv[4 + t] = b1[t]; }
+            const bf16_t* xp = sX + (py * (WB_TW + 2) + px0) * SXP + xoff;
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) {
+                const int tap = t * G + grp;
+                if (tap < 9) {
+                    const bf16_t* ap = xp + ((tap / 3) * (WB_TW + 2) + tap % 3) * SXP;
+                    const bf16x4 a0 = lds_read_tr16(ap), a1 = lds_read_tr16(ap + 4 * SXP);
+                    bf16x8 av;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { av[e] = a0[e]; av[4 + e] = a1[e]; }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (do_bias) a.bslabs[(size_t)blockIdx.y * a.Cout + co0 + tid] = bsum;
+    float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+        const int tap = t * G + grp;
+        if (tap >= 9) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = acc[t][r];
+        }
+    }
+}
+
+bool conv_bf16_wgrad_supported(const ConvGeom& g) {
+    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin % 32) == 0 &&
+           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+}
+static void wb_plan(const ConvGeom& g, int& MT, int& NTW, int& groups, int& ntiles, int& P) {
+    MT = (g.Cin % 64) == 0 ? 2 : 1;
+    NTW = (g.Cout % 64) == 0 ? 2 : 1;
+    groups = (g.Cin / (32 * MT)) * (g.Cout / (32 * NTW));
+    const int th = wb_th(MT, NTW);
+    ntiles = g.B * ((g.H + th - 1) / th) * ((g.W + WB_TW - 1) / WB_TW);
+    P = 512 / groups;
+    if (P < 1) P = 1;
+    if (P > ntiles) P = ntiles;
+}
+size_t conv_bf16_wgrad_workspace(const ConvGeom& g) {
+    int MT, NTW, groups, ntiles, P;
+    wb_plan(g, MT, NTW, groups, ntiles, P);
+    return sizeof(float) * ((size_t)P * 9 * g.Cin * g.Cout + (size_t)P * g.Cout);
+}
+static int wb_ysplit(size_t n4, int P) {       // the rule of conv_mfma.hip's wgrad_reduce_launch
+    unsigned gx = dasr_cdiv(n4, 256);
+    int ysplit = 1;
+    while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
+    return ysplit;
+}
+int conv_bf16_wgrad(const ConvGeom& g, const bf16_t* x, const bf16_t* dconv, float* dw, float* dbias, void* workspace,
+                    void* stream) {
+    int MT, NTW, groups, ntiles, P;
+    wb_plan(g, MT, NTW, groups, ntiles, P);
+    const size_t nW = (size_t)9 * g.Cin * g.Cout;
+    float* slabs = (float*)workspace;
+    float* bslabs = dbias ? slabs + (size_t)P * nW : nullptr;
+    const bool ysplit = wb_ysplit(nW / 4, P) > 1;
+    WgradBf16Args a{x, dconv, slabs, bslabs, ysplit ? dw : nullptr, ysplit ? nW : 0, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
+    const int th = wb_th(MT, NTW);
+    const size_t lds = sizeof(bf16_t) * (size_t)((th + 2) * (WB_TW + 2) * wb_stride(32 * MT) + th * WB_TW * wb_stride(32 * NTW));
+    dim3 grid(groups, P);
+    if (MT == 2 && NTW == 2)      DASR_LAUNCH((k_conv3x3_wgrad_bf16<2, 2>), grid, dim3(256), lds, stream, a);
+    else if (MT == 2 && NTW == 1) DASR_LAUNCH((k_conv3x3_wgrad_bf16<2, 1>), grid, dim3(256), lds, stream, a);
+    else if (MT == 1 && NTW == 2) DASR_LAUNCH((k_conv3x3_wgrad_bf16<1, 2>), grid, dim3(256), lds, stream, a);
+    else                          DASR_LAUNCH((k_conv3x3_wgrad_bf16<1, 1>), grid, dim3(256), lds, stream, a);
+    return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit, bslabs, dbias, g.Cout);
+}

@@ -4,6 +4,7 @@
 // reads the incoming gradient and the saved activation once (ReLU backward fused) and reduces over pixels.
 // Lane layout: a lane owns 4 consecutive output channels (float4), 256-byte runs per 16 lanes.
 #include "dasr_common.h"
+#include "bf16.h"
 #include "conv_kernels.h"
 
 // Both kernels walk image ROWS: a workgroup stages the three depth-map rows around row (b, y) in LDS (zero padded,
@@ -20,8 +21,10 @@ __device__ __forceinline__ void c1_stage_rows(const float* __restrict__ x, float
     }
 }
 
+// T = storage type of the Cout-channel activation (y, dy, yact): float or bf16_t; the depth map and the kernel are fp32
+template <typename T>
 __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                        const float* __restrict__ bias, T* __restrict__ y, int B,
                                                         int H, int W, int Cout, int act) {
     DASR_DYN_SMEM(smem);
     float* sRow = (float*)smem;                    // [3][W+2]
@@ -37,7 +40,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict_
         c1_stage_rows(x, sRow, b, py, H, W);
         __syncthreads();
         if (pl >= npl) continue;
-        float* yrow = y + ((size_t)row * W) * Cout + 4 * q;
+        T* yrow = y + ((size_t)row * W) * Cout + 4 * q;
         for (int px = pl; px < W; px += npl) {
             float4 acc = bv;
 #pragma unroll
@@ -48,14 +51,15 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict_
             }
             acc.x = dasr_act(acc.x, act); acc.y = dasr_act(acc.y, act);
             acc.z = dasr_act(acc.z, act); acc.w = dasr_act(acc.w, act);
-            *(float4*)(yrow + (size_t)px * Cout) = acc;
+            st4(yrow + (size_t)px * Cout, acc);
         }
     }
 }
 
 // dw[tap][co] = sum_p x[p+tap] * dconv[p][co], dbias[co] = sum_p dconv[p][co], dconv = dy * act'(y)
-__global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          const float* __restrict__ yact, float* __restrict__ dw,
+template <typename T>
+__global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restrict__ x, const T* __restrict__ dy,
+                                                          const T* __restrict__ yact, float* __restrict__ dw,
                                                           float* __restrict__ dbias, int B, int H, int W, int Cout,
                                                           int act) {
     DASR_DYN_SMEM(smem);
@@ -72,8 +76,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restric
         c1_stage_rows(x, sRow, b, py, H, W);
         __syncthreads();
         if (pl >= npl) continue;
-        const float* grow = dy + ((size_t)row * W) * Cout + 4 * q;
-        const float* arow = yact ? yact + ((size_t)row * W) * Cout + 4 * q : nullptr;
+        const T* grow = dy + ((size_t)row * W) * Cout + 4 * q;
+        const T* arow = yact ? yact + ((size_t)row * W) * Cout + 4 * q : nullptr;
         for (int px0 = pl; px0 < W; px0 += 4 * npl) {
             // four pixels per trip: all eight 16-byte loads are issued before the first is consumed (clamped
             // addresses, contributions of pixels past the row end are zeroed)
@@ -81,8 +85,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restric
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int px = px0 + u * npl < W ? px0 + u * npl : W - 1;
-                gq[u] = *(const float4*)(grow + (size_t)px * Cout);
-                yq[u] = arow ? *(const float4*)(arow + (size_t)px * Cout) : make_float4(1.f, 1.f, 1.f, 1.f);
+                gq[u] = ld4(grow + (size_t)px * Cout);
+                yq[u] = arow ? ld4(arow + (size_t)px * Cout) : make_float4(1.f, 1.f, 1.f, 1.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -128,21 +132,37 @@ bool conv_c1_supported(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && g.Cin == 1 && (g.Cout % 4) == 0 &&
            g.Cout <= 1024 && (256 % (g.Cout / 4)) == 0 && g.H == g.Ho && g.W == g.Wo && g.W <= C1_MAXW;
 }
-int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream) {
+template <typename T>
+static int conv_c1_fwd_impl(const ConvGeom& g, const float* x, const float* w, const float* bias, T* y, int act, void* stream) {
     unsigned grid = (unsigned)(g.B * g.H);
     if (grid > 256 * 8) grid = 256 * 8;
-    DASR_LAUNCH(k_conv3x3_c1_fwd, dim3(grid), dim3(256), sizeof(float) * 3 * (g.W + 2), stream, x, w, bias, y, g.B, g.H,
+    DASR_LAUNCH((k_conv3x3_c1_fwd<T>), dim3(grid), dim3(256), sizeof(float) * 3 * (g.W + 2), stream, x, w, bias, y, g.B, g.H,
                 g.W, g.Cout, act);
     DASR_RETURN_LAUNCH_STATUS();
 }
+int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream) {
+    return conv_c1_fwd_impl<float>(g, x, w, bias, y, act, stream);
+}
+int conv_c1_fwd_bf16(const ConvGeom& g, const float* x, const float* w, const float* bias, bf16_t* y, int act, void* stream) {
+    return conv_c1_fwd_impl<bf16_t>(g, x, w, bias, y, act, stream);
+}
 // yact may be null (dy is already the gradient w.r.t. the convolution output)
-int conv_c1_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* yact, int act, float* dw, float* dbias,
-                  void* stream) {
+template <typename T>
+static int conv_c1_wgrad_impl(const ConvGeom& g, const float* x, const T* dy, const T* yact, int act, float* dw, float* dbias,
+                              void* stream) {
     // one launch clears both accumulators (two memsets were two more dispatches on a 130 us kernel)
     DASR_LAUNCH(k_c1_zero, dim3(dasr_cdiv((size_t)10 * g.Cout, 256)), dim3(256), 0, stream, dw, 9 * g.Cout, dbias, g.Cout);
     unsigned grid = (unsigned)(g.B * g.H);
     if (grid > 512) grid = 512;         // two workgroups per CU; more only adds float atomics at the end (measured)
-    DASR_LAUNCH(k_conv3x3_c1_wgrad, dim3(grid), dim3(256), sizeof(float) * (256 * 40 + 3 * (g.W + 2)), stream, x, dy, yact,
+    DASR_LAUNCH((k_conv3x3_c1_wgrad<T>), dim3(grid), dim3(256), sizeof(float) * (256 * 40 + 3 * (g.W + 2)), stream, x, dy, yact,
                 dw, dbias, g.B, g.H, g.W, g.Cout, act);
     DASR_RETURN_LAUNCH_STATUS();
+}
+int conv_c1_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* yact, int act, float* dw, float* dbias,
+                  void* stream) {
+    return conv_c1_wgrad_impl<float>(g, x, dy, yact, act, dw, dbias, stream);
+}
+int conv_c1_wgrad_bf16(const ConvGeom& g, const float* x, const bf16_t* dy, const bf16_t* yact, int act, float* dw,
+                       float* dbias, void* stream) {
+    return conv_c1_wgrad_impl<bf16_t>(g, x, dy, yact, act, dw, dbias, stream);
 }

@@ -3,6 +3,7 @@
 // implicit-GEMM kernels (conv_mfma.hip) do not cover: the strided / transposed encoder layers, the
 // 1- and 3-channel inputs, and odd channel counts.  dasr_conv2d_* in conv_api.hip dispatch between them.
 #include "dasr_common.h"
+#include "bf16.h"
 #include "conv_kernels.h"
 
 // ------------------------------------------------------------------------------------------ forward
@@ -47,8 +48,9 @@ __global__ void __launch_bounds__(256) k_conv_direct_fwd(ConvGeom g, const float
     }
 }
 
-__global__ void __launch_bounds__(256) k_conv_epilogue_bwd(ConvGeom g, const float* __restrict__ dy,
-                                                           const float* __restrict__ y, float* __restrict__ dconv,
+template <typename T>
+__global__ void __launch_bounds__(256) k_conv_epilogue_bwd(ConvGeom g, const T* __restrict__ dy,
+                                                           const T* __restrict__ y, T* __restrict__ dconv,
                                                            int act, int ps_r) {
     size_t n = (size_t)g.B * g.Ho * g.Wo * g.Cout;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(256) k_conv_epilogue_bwd(ConvGeom g, const flo
         size_t pix = idx / g.Cout;
         int ox = (int)(pix % g.Wo), oy = (int)((pix / g.Wo) % g.Ho), b = (int)(pix / ((size_t)g.Wo * g.Ho));
         size_t o = conv_out_index(g, b, oy, ox, co, ps_r);
-        dconv[idx] = dy[o] * dasr_act_grad_from_out(y[o], act);
+        st1(dconv + idx, ld1(dy + o) * dasr_act_grad_from_out(ld1(y + o), act));
     }
 }
 
@@ -184,62 +186,70 @@ int conv_direct_fwd(const ConvGeom& g, const float* x, const float* w, const flo
 }
 // Fast forms of the above (the generic kernel spends three 64-bit divisions and a scalar load pair per element).
 // No PixelShuffle: the index map is the identity -> float4 streaming.
-__global__ void __launch_bounds__(256) k_conv_epilogue_bwd_flat4(const float* __restrict__ dy, const float* __restrict__ y,
-                                                                 float* __restrict__ dconv, size_t n4, int act) {
+template <typename T>
+__global__ void __launch_bounds__(256) k_conv_epilogue_bwd_flat4(const T* __restrict__ dy, const T* __restrict__ y,
+                                                                 T* __restrict__ dconv, size_t n4, int act) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 d = ((const float4*)dy)[i], v = ((const float4*)y)[i];
-        ((float4*)dconv)[i] = make_float4(d.x * dasr_act_grad_from_out(v.x, act), d.y * dasr_act_grad_from_out(v.y, act),
-                                          d.z * dasr_act_grad_from_out(v.z, act), d.w * dasr_act_grad_from_out(v.w, act));
+        const float4 d = ld4(dy + 4 * i), v = ld4(y + 4 * i);
+        st4(dconv + 4 * i, make_float4(d.x * dasr_act_grad_from_out(v.x, act), d.y * dasr_act_grad_from_out(v.y, act),
+                                       d.z * dasr_act_grad_from_out(v.z, act), d.w * dasr_act_grad_from_out(v.w, act)));
     }
 }
 // PixelShuffle(R): one thread per (conv pixel, shuffled channel c): R*R coalesced 4-byte reads of dy / y (consecutive
 // lanes = consecutive c), one contiguous run of R*R floats written (co = c*R*R + i*R + j).  blockIdx.y = conv row
 // (b*Ho + oy), so the only division left is e / Cq.
-template <int R>
-__global__ void __launch_bounds__(256) k_conv_epilogue_bwd_ps(const float* __restrict__ dy, const float* __restrict__ y,
-                                                              float* __restrict__ dconv, int Wo, int Cq, int act) {
+template <int R, typename T>
+__global__ void __launch_bounds__(256) k_conv_epilogue_bwd_ps(const T* __restrict__ dy, const T* __restrict__ y,
+                                                              T* __restrict__ dconv, int Wo, int Cq, int act) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= Wo * Cq) return;
     const int ox = e / Cq, c = e - ox * Cq;
     const size_t row = blockIdx.y;                                        // b*Ho + oy
     const size_t srow = (size_t)Wo * R * Cq;                              // floats per shuffled row
-    const float* dyp = dy + row * R * srow + (size_t)ox * R * Cq + c;
-    const float* yp = y + row * R * srow + (size_t)ox * R * Cq + c;
+    const T* dyp = dy + row * R * srow + (size_t)ox * R * Cq + c;
+    const T* yp = y + row * R * srow + (size_t)ox * R * Cq + c;
     float out[R * R];
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const size_t o = (size_t)i * srow + (size_t)j * Cq;
-            out[i * R + j] = dyp[o] * dasr_act_grad_from_out(yp[o], act);
+            out[i * R + j] = ld1(dyp + o) * dasr_act_grad_from_out(ld1(yp + o), act);
         }
-    float* dst = dconv + (row * Wo + ox) * (size_t)(Cq * R * R) + (size_t)c * (R * R);
+    T* dst = dconv + (row * Wo + ox) * (size_t)(Cq * R * R) + (size_t)c * (R * R);
     if (R == 2) {
-        *(float4*)dst = make_float4(out[0], out[1], out[2], out[3]);
+        st4(dst, make_float4(out[0], out[1], out[2], out[3]));
     } else {
 #pragma unroll
-        for (int q = 0; q < R * R; ++q) dst[q] = out[q];
+        for (int q = 0; q < R * R; ++q) st1(dst + q, out[q]);
     }
 }
 
-int conv_epilogue_bwd(const ConvGeom& g, const float* dy, const float* y, float* dconv, int act, int ps_r,
-                      void* stream) {
+template <typename T>
+static int conv_epilogue_bwd_impl(const ConvGeom& g, const T* dy, const T* y, T* dconv, int act, int ps_r, void* stream) {
     size_t n = (size_t)g.B * g.Ho * g.Wo * g.Cout;
     const size_t rows = (size_t)g.B * g.Ho;
     if (ps_r <= 1 && (n % 4) == 0) {
-        DASR_LAUNCH(k_conv_epilogue_bwd_flat4, dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, dy, y, dconv, n / 4, act);
+        DASR_LAUNCH((k_conv_epilogue_bwd_flat4<T>), dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, dy, y, dconv, n / 4, act);
     } else if ((ps_r == 2 || ps_r == 3) && (g.Cout % (ps_r * ps_r)) == 0 && rows <= 65535 &&
                (size_t)g.Wo * (g.Cout / (ps_r * ps_r)) < (1u << 30)) {
         const int Cq = g.Cout / (ps_r * ps_r);
         const dim3 grid(dasr_cdiv((size_t)g.Wo * Cq, 256), (unsigned)rows);
         if (ps_r == 2)
-            DASR_LAUNCH((k_conv_epilogue_bwd_ps<2>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act);
+            DASR_LAUNCH((k_conv_epilogue_bwd_ps<2, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act);
         else
-            DASR_LAUNCH((k_conv_epilogue_bwd_ps<3>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act);
+            DASR_LAUNCH((k_conv_epilogue_bwd_ps<3, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act);
     } else {
-        DASR_LAUNCH(k_conv_epilogue_bwd, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, g, dy, y, dconv, act, ps_r);
+        DASR_LAUNCH((k_conv_epilogue_bwd<T>), dim3(dasr_ew_grid(n)), dim3(256), 0, stream, g, dy, y, dconv, act, ps_r);
     }
     DASR_RETURN_LAUNCH_STATUS();
+}
+int conv_epilogue_bwd(const ConvGeom& g, const float* dy, const float* y, float* dconv, int act, int ps_r, void* stream) {
+    return conv_epilogue_bwd_impl<float>(g, dy, y, dconv, act, ps_r, stream);
+}
+int conv_epilogue_bwd_bf16(const ConvGeom& g, const bf16_t* dy, const bf16_t* y, bf16_t* dconv, int act, int ps_r,
+                           void* stream) {
+    return conv_epilogue_bwd_impl<bf16_t>(g, dy, y, dconv, act, ps_r, stream);
 }
 int conv_direct_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream) {
     size_t n = (size_t)g.B * g.H * g.W * g.Cin;

@@ -1,6 +1,7 @@
 // conv_kernels.h — geometry struct and internal entry points shared by the convolution sources.
 #pragma once
 #include "dasr_common.h"
+#include "bf16.h"
 
 struct ConvGeom {
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed;
@@ -66,3 +67,24 @@ bool conv_c1_supported(const ConvGeom& g);
 int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream);
 int conv_c1_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* yact, int act, float* dw, float* dbias,
                   void* stream);
+
+// ---- bf16 activations (mixed-precision path) ---------------------------------------------------------------------
+// conv_bf16_mfma.hip (3x3, stride 1, pad 1, Cin % 32 == 0, Cout % 32 == 0; bf16 x, packed bf16 w, fp32 bias / dw / dbias)
+bool conv_bf16_supported(const ConvGeom& g);
+bool conv_bf16_dgrad_supported(const ConvGeom& g);
+bool conv_bf16_wgrad_supported(const ConvGeom& g);
+int conv_bf16_fwd(const ConvGeom& g, const bf16_t* x, const bf16_t* w, const float* bias, const bf16_t* residual,
+                  bf16_t* y, int act, int ps_r, void* stream);
+int conv_bf16_dgrad(const ConvGeom& g, const bf16_t* dconv, const bf16_t* w, bf16_t* dx, int accumulate, void* stream);
+size_t conv_bf16_wgrad_workspace(const ConvGeom& g);
+int conv_bf16_wgrad(const ConvGeom& g, const bf16_t* x, const bf16_t* dconv, float* dw, float* dbias, void* workspace,
+                    void* stream);
+// the same kernels as their fp32 namesakes, instantiated for bf16 activations
+int conv_epilogue_bwd_bf16(const ConvGeom& g, const bf16_t* dy, const bf16_t* y, bf16_t* dconv, int act, int ps_r,
+                           void* stream);
+int conv_c1_fwd_bf16(const ConvGeom& g, const float* x, const float* w, const float* bias, bf16_t* y, int act, void* stream);
+int conv_c1_wgrad_bf16(const ConvGeom& g, const float* x, const bf16_t* dy, const bf16_t* yact, int act, float* dw,
+                       float* dbias, void* stream);
+int conv9_mfma_fwd_bf16(const ConvGeom& g, const bf16_t* x, const float* w, const float* bias, float* y, void* stream);
+int conv9_mfma_dgrad_bf16(const ConvGeom& g, const float* dconv, const float* w, bf16_t* dx, int accumulate, void* stream);
+int conv9_mfma_wgrad_bf16(const ConvGeom& g, const bf16_t* x, const float* dconv, float* dw, void* workspace, void* stream);

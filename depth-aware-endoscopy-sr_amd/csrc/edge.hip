@@ -2,6 +2,7 @@
 // All HBM-bound, grid-stride, one element per thread iteration (3-channel tensors: the wide path
 // is the NHWC side, which is written/read as consecutive floats across lanes).
 #include "dasr_common.h"
+#include "bf16.h"
 
 extern "C" int dasr_version(void) { return 100; }
 extern "C" int dasr_is_device_build(void) { return DASR_DEVICE_BUILD; }
@@ -144,4 +145,54 @@ extern "C" int dasr_copy(float* dst, const float* src, size_t n, void* stream) {
     DASR_CHECK_PTR(dst); DASR_CHECK_PTR(src);
     DASR_CHECK_SHAPE(n > 0);
     return (int)hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+
+// ---- bf16 activations (mixed-precision path): elementwise helpers on 4-element groups (n % 4 == 0: every activation
+// tensor of the net has a channel count that is a multiple of 4), fp32 arithmetic, one rounding on the store
+__global__ void k_add_bf16(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 x = ld4(a + 4 * i), y = ld4(b + 4 * i);
+        st4(out + 4 * i, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
+    }
+}
+// dst (fp32 or bf16) += src (bf16 or fp32) / dst = src: the casts at the fp32 encoder <-> bf16 trunk boundary
+template <typename TD, typename TS, bool ACC>
+__global__ void k_cast4(TD* __restrict__ dst, const TS* __restrict__ src, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = ld4(src + 4 * i);
+        if (ACC) {
+            const float4 d = ld4(dst + 4 * i);
+            v = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, v.w + d.w);
+        }
+        st4(dst + 4 * i, v);
+    }
+}
+extern "C" int dasr_add_bf16(const unsigned short* a, const unsigned short* b, unsigned short* out, size_t n, void* stream) {
+    DASR_CHECK_PTR(a); DASR_CHECK_PTR(b); DASR_CHECK_PTR(out);
+    DASR_CHECK_SHAPE(n > 0 && (n % 4) == 0);
+    DASR_LAUNCH(k_add_bf16, dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out,
+                n / 4);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+extern "C" int dasr_accumulate_bf16(unsigned short* dst, const unsigned short* src, size_t n, void* stream) {
+    DASR_CHECK_PTR(dst); DASR_CHECK_PTR(src);
+    DASR_CHECK_SHAPE(n > 0 && (n % 4) == 0);
+    DASR_LAUNCH((k_cast4<bf16_t, bf16_t, true>), dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, (bf16_t*)dst,
+                (const bf16_t*)src, n / 4);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+extern "C" int dasr_cast_f32_to_bf16(const float* src, unsigned short* dst, size_t n, void* stream) {
+    DASR_CHECK_PTR(dst); DASR_CHECK_PTR(src);
+    DASR_CHECK_SHAPE(n > 0 && (n % 4) == 0);
+    DASR_LAUNCH((k_cast4<bf16_t, float, false>), dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, (bf16_t*)dst, src, n / 4);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+extern "C" int dasr_cast_bf16_to_f32(const unsigned short* src, float* dst, int accumulate, size_t n, void* stream) {
+    DASR_CHECK_PTR(dst); DASR_CHECK_PTR(src);
+    DASR_CHECK_SHAPE(n > 0 && (n % 4) == 0);
+    if (accumulate)
+        DASR_LAUNCH((k_cast4<float, bf16_t, true>), dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, dst, (const bf16_t*)src, n / 4);
+    else
+        DASR_LAUNCH((k_cast4<float, bf16_t, false>), dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, dst, (const bf16_t*)src, n / 4);
+    DASR_RETURN_LAUNCH_STATUS();
 }

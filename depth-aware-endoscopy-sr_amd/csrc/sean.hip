@@ -15,6 +15,7 @@
 // LDS once per workgroup; each thread owns one channel lane and walks the tile's pixels, so t / gb2 /
 // out accesses are 256-byte coalesced rows and the LDS reads of D are conflict-free (lane = channel).
 #include "dasr_common.h"
+#include "bf16.h"
 
 #define SEAN_TH 8
 #define SEAN_TW 32
@@ -70,13 +71,16 @@ __device__ __forceinline__ void sean_dynconv(const float* sD, const float* sM, i
     b1 = ab;
 }
 
-__global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const float* __restrict__ t,
+// T = storage type of the activation tensors (t, gb2, residual, out, and their gradients): float, or bf16_t on the
+// mixed-precision path; everything per-(b,c), D, the biases and all arithmetic stay fp32.
+template <typename T>
+__global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const T* __restrict__ t,
                                                   const float* __restrict__ mean, const float* __restrict__ var,
-                                                  const float* __restrict__ gb2, const float* __restrict__ mask,
+                                                  const T* __restrict__ gb2, const float* __restrict__ mask,
                                                   const float* __restrict__ D, const float* __restrict__ bias_g,
                                                   const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
-                                                  const float* __restrict__ alpha_b, const float* __restrict__ residual,
-                                                  float* __restrict__ out, int relu, float eps,
+                                                  const float* __restrict__ alpha_b, const T* __restrict__ residual,
+                                                  T* __restrict__ out, int relu, float eps,
                                                   const int* __restrict__ onehot_flag) {
     if (onehot_flag && *onehot_flag == 0) return;   // one-hot masks: k_sean_fwd_onehot does the work
     DASR_DYN_SMEM(smem);
@@ -103,21 +107,16 @@ __global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const float* __res
         sean_dynconv(sD, sM, g.K, ly, lx, cl, g1, b1);
         g1 += bg;
         b1 += bb;
-        float g2 = gb2[p * 2 * g.C + c], b2 = gb2[p * 2 * g.C + g.C + c];
+        float g2 = ld1(gb2 + p * 2 * g.C + c), b2 = ld1(gb2 + p * 2 * g.C + g.C + c);
         float gam = a_g * g1 + (1.f - a_g) * g2;
         float bet = a_b * b1 + (1.f - a_b) * b2;
-        float xh = (t[p * g.C + c] - mu) * s;
+        float xh = (ld1(t + p * g.C + c) - mu) * s;
         float o = xh * (1.f + gam) + bet;
-        if (residual) o += residual[p * g.C + c];
+        if (residual) o += ld1(residual + p * g.C + c);
         if (relu) o = o > 0.f ? o : 0.f;
-        out[p * g.C + c] = o;
+        st1(out + p * g.C + c, o);
     }
 }
-
-extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var, const float* gb2, const float* mask,
-                             const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_g,
-                             const float* bias_b, const float* alpha_g, const float* alpha_b, const float* residual,
-                             float* out, int relu, int B, int H, int W, int C, int K, float eps, void* stream);
 
 // ---------------------------------------------------------------------------------------- backward
 // Pass A (per tile): g0 = dout*relu'(out); dgb2, dres; dxhat -> dt (temporarily); per-(b,c) sums
@@ -125,18 +124,19 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
 //   atomic per (tap,k,c) per workgroup).
 // Pass B (elementwise): dt = s*(dxhat - S1/N) + s'(var)*(2/N)*(t-mean)*S2.
 // workspace: S [B][C][2] floats.
-__global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const float* __restrict__ dout,
-                                                    const float* __restrict__ out, const float* __restrict__ t,
+template <typename T>
+__global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restrict__ dout,
+                                                    const T* __restrict__ out, const T* __restrict__ t,
                                                     const float* __restrict__ mean, const float* __restrict__ var,
-                                                    const float* __restrict__ gb2, const float* __restrict__ mask,
+                                                    const T* __restrict__ gb2, const float* __restrict__ mask,
                                                     const float* __restrict__ D, const float* __restrict__ bias_g,
                                                     const float* __restrict__ bias_b,
                                                     const float* __restrict__ alpha_g,
-                                                    const float* __restrict__ alpha_b, float* __restrict__ dt,
-                                                    float* __restrict__ dgb2, float* __restrict__ dD,
+                                                    const float* __restrict__ alpha_b, T* __restrict__ dt,
+                                                    T* __restrict__ dgb2, float* __restrict__ dD,
                                                     float* __restrict__ dbias_g, float* __restrict__ dbias_b,
                                                     float* __restrict__ dalpha_g, float* __restrict__ dalpha_b,
-                                                    float* __restrict__ dres, float* __restrict__ S, int relu,
+                                                    T* __restrict__ dres, float* __restrict__ S, int relu,
                                                     float eps, const int* __restrict__ onehot_flag) {
     if (onehot_flag && *onehot_flag == 0) return;
     DASR_DYN_SMEM(smem);
@@ -166,20 +166,20 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const float* __r
             int y = y0 + ly, x = x0 + lx;
             if (y >= g.H || x >= g.W) continue;
             size_t p = ((size_t)b * g.H + y) * g.W + x;
-            float g0 = dout[p * g.C + c];
-            if (relu && !(out[p * g.C + c] > 0.f)) g0 = 0.f;
-            if (dres) dres[p * g.C + c] = g0;
+            float g0 = ld1(dout + p * g.C + c);
+            if (relu && !(ld1(out + p * g.C + c) > 0.f)) g0 = 0.f;
+            if (dres) st1(dres + p * g.C + c, g0);
             float g1, b1;
             sean_dynconv(sD, sM, K, ly, lx, cl, g1, b1);
             g1 += bg;
             b1 += bb;
-            float g2 = gb2[p * 2 * g.C + c], b2 = gb2[p * 2 * g.C + g.C + c];
+            float g2 = ld1(gb2 + p * 2 * g.C + c), b2 = ld1(gb2 + p * 2 * g.C + g.C + c);
             float gam = a_g * g1 + (1.f - a_g) * g2;
-            float xc = t[p * g.C + c] - mu;
+            float xc = ld1(t + p * g.C + c) - mu;
             float xh = xc * s;
             float dgam = g0 * xh, dbet = g0;
-            dgb2[p * 2 * g.C + c] = (1.f - a_g) * dgam;
-            dgb2[p * 2 * g.C + g.C + c] = (1.f - a_b) * dbet;
+            st1(dgb2 + p * 2 * g.C + c, (1.f - a_g) * dgam);
+            st1(dgb2 + p * 2 * g.C + g.C + c, (1.f - a_b) * dbet);
             dag = fmaf(dgam, g1 - g2, dag);
             dab = fmaf(dbet, b1 - b2, dab);
             float dg1 = a_g * dgam, db1 = a_b * dbet;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const float* __r
                 }
             }
             float dxh = g0 * (1.f + gam);
-            dt[p * g.C + c] = dxh;
+            st1(dt + p * g.C + c, dxh);
             S1 += dxh;
             S2 = fmaf(dxh, xc, S2);
         }
@@ -238,9 +238,10 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const float* __r
 
 // dt = s*(dxhat - S1/N) + s'(var)*(2/N)*(t-mean)*S2; float4 per lane when C % 4 == 0 (per-(b,c) constants are
 // recomputed from mean/var/S: 4 channels x 4 small loads, all L1/L2 hits)
-__global__ void __launch_bounds__(256) k_sean_bwd_b(const float* __restrict__ t, const float* __restrict__ mean,
+template <typename T>
+__global__ void __launch_bounds__(256) k_sean_bwd_b(const T* __restrict__ t, const float* __restrict__ mean,
                                                     const float* __restrict__ var, const float* __restrict__ S,
-                                                    float* __restrict__ dt, int HW, int C, size_t n, float eps) {
+                                                    T* __restrict__ dt, int HW, int C, size_t n, float eps) {
     const float invN = 1.0f / (float)HW;
     if ((C & 3) == 0) {
         const size_t n4 = n >> 2;
@@ -249,8 +250,8 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const float* __restrict__ t,
             const int c = 4 * (int)(i % C4);
             const size_t b = i / ((size_t)C4 * HW);
             const size_t bc = b * C + c;
-            const float4 tv = *(const float4*)(t + 4 * i);
-            float4 dv = *(const float4*)(dt + 4 * i);
+            const float4 tv = ld4(t + 4 * i);
+            float4 dv = ld4(dt + 4 * i);
             const float4 mu = *(const float4*)(mean + bc), vr = *(const float4*)(var + bc);
             const float4 s01 = *(const float4*)(S + 2 * bc), s23 = *(const float4*)(S + 2 * bc + 4);
             dv.x = dasr_double_in_scale(vr.x, eps) * (dv.x - s01.x * invN) +
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const float* __restrict__ t,
                    dasr_double_in_dscale(vr.z, eps) * 2.f * invN * (tv.z - mu.z) * s23.y;
             dv.w = dasr_double_in_scale(vr.w, eps) * (dv.w - s23.z * invN) +
                    dasr_double_in_dscale(vr.w, eps) * 2.f * invN * (tv.w - mu.w) * s23.w;
-            *(float4*)(dt + 4 * i) = dv;
+            st4(dt + 4 * i, dv);
         }
         return;
     }
@@ -271,8 +272,8 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const float* __restrict__ t,
         size_t bc = b * C + c;
         float v = var[bc];
         float s = dasr_double_in_scale(v, eps), ds = dasr_double_in_dscale(v, eps);
-        float xc = t[i] - mean[bc];
-        dt[i] = s * (dt[i] - S[bc * 2] * invN) + ds * 2.f * invN * xc * S[bc * 2 + 1];
+        float xc = ld1(t + i) - mean[bc];
+        st1(dt + i, s * (ld1(dt + i) - S[bc * 2] * invN) + ds * 2.f * invN * xc * S[bc * 2 + 1]);
     }
 }
 
@@ -280,9 +281,10 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const float* __restrict__ t,
 // Same as the float4 branch above for C4 = C/4 dividing 256: blockIdx.y = sample, a thread keeps ONE channel quad
 // and walks the pixels, so the per-(b,c) factors (two rsqrt-style scales and their derivative: 16 sqrt/div per float4
 // in the kernel above, plus two 64-bit divisions for the index) are computed once per thread.
-__global__ void __launch_bounds__(256) k_sean_bwd_b_rows(const float* __restrict__ t, const float* __restrict__ mean,
+template <typename T>
+__global__ void __launch_bounds__(256) k_sean_bwd_b_rows(const T* __restrict__ t, const float* __restrict__ mean,
                                                          const float* __restrict__ var, const float* __restrict__ S,
-                                                         float* __restrict__ dt, int HW, int C, float eps) {
+                                                         T* __restrict__ dt, int HW, int C, float eps) {
     const int C4 = C >> 2, q = threadIdx.x % C4, pl = threadIdx.x / C4, npl = 256 / C4;
     const int b = blockIdx.y, c = 4 * q;
     const float invN = 1.0f / (float)HW;
@@ -295,17 +297,17 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b_rows(const float* __restrict
     const float4 D2 = make_float4(dasr_double_in_dscale(vr.x, eps) * 2.f * invN, dasr_double_in_dscale(vr.y, eps) * 2.f * invN,
                                   dasr_double_in_dscale(vr.z, eps) * 2.f * invN, dasr_double_in_dscale(vr.w, eps) * 2.f * invN);
     const float4 S1 = make_float4(s01.y, s01.w, s23.y, s23.w);
-    const float* tb = t + (size_t)b * HW * C + c;
-    float* db = dt + (size_t)b * HW * C + c;
+    const T* tb = t + (size_t)b * HW * C + c;
+    T* db = dt + (size_t)b * HW * C + c;
     for (int p = blockIdx.x * npl + pl; p < HW; p += gridDim.x * npl) {
-        const float4 tv = *(const float4*)(tb + (size_t)p * C);
-        float4 dv = *(const float4*)(db + (size_t)p * C);
+        const float4 tv = ld4(tb + (size_t)p * C);
+        float4 dv = ld4(db + (size_t)p * C);
         // same expression order as the general kernel: s*(dv - S0/N) + (ds*2/N)*(t - mu)*S1
         dv.x = A.x * (dv.x - Bm.x) + D2.x * (tv.x - mu.x) * S1.x;
         dv.y = A.y * (dv.y - Bm.y) + D2.y * (tv.y - mu.y) * S1.y;
         dv.z = A.z * (dv.z - Bm.z) + D2.z * (tv.z - mu.z) * S1.z;
         dv.w = A.w * (dv.w - Bm.w) + D2.w * (tv.w - mu.w) * S1.w;
-        *(float4*)(db + (size_t)p * C) = dv;
+        st4(db + (size_t)p * C, dv);
     }
 }
 
@@ -357,18 +359,6 @@ extern "C" int dasr_mask_compress(const float* mask, unsigned char* region, int*
 }
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
-__device__ __forceinline__ float4 ld_nt4(const float* p) {
-    f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
-    return make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void st_nt4(float* p, float4 v) {
-#if DASR_DEVICE_BUILD
-    f32x4 w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, (f32x4*)p);
-#else
-    *(float4*)p = v;
-#endif
-}
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // Stage D[b] (channel slice c0..c0+63) as [18][K+1][64] with a zero row K ("no region": outside the image
@@ -471,19 +461,19 @@ __device__ __forceinline__ void sean_gather_folded(const float* sD, const unsign
 // two barriers are covered by loads in flight.
 struct SeanTile { int b, y0, x0; };
 
-template <bool RELU, bool HAS_RES>
-__global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const float* __restrict__ t,
+template <bool RELU, bool HAS_RES, typename TA>
+__global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const TA* __restrict__ t,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ var,
-                                                            const float* __restrict__ gb2,
+                                                            const TA* __restrict__ gb2,
                                                             const unsigned char* __restrict__ region,
                                                             const int* __restrict__ flag, const float* __restrict__ D,
                                                             const float* __restrict__ bias_g,
                                                             const float* __restrict__ bias_b,
                                                             const float* __restrict__ alpha_g,
                                                             const float* __restrict__ alpha_b,
-                                                            const float* __restrict__ residual,
-                                                            float* __restrict__ out, float eps, int tiles_per_wg) {
+                                                            const TA* __restrict__ residual,
+                                                            TA* __restrict__ out, float eps, int tiles_per_wg) {
     DASR_DYN_SMEM(smem);
     constexpr int TH = SF_TH, NG = TH;                         // NG groups of 8 pixels per wave and tile (TH/4 rows x 4)
     const int K1 = g.K + 1;
@@ -516,17 +506,17 @@ __global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const fl
         const size_t row = ((size_t)T.b * g.H + y) * g.W;                       // scalar
         const char* trow = (const char*)(t + row * g.C);
         const char* grow = (const char*)(gb2 + row * 2 * g.C);
-        const char* brow = grow + (size_t)g.C * 4;                              // beta half of the (gamma2 | beta2) pair
+        const char* brow = grow + (size_t)g.C * sizeof(TA);                      // beta half of the (gamma2 | beta2) pair
         const char* rrow = HAS_RES ? (const char*)(residual + row * g.C) : nullptr;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const unsigned x = (unsigned)imin(T.x0 + 8 * (grp & 3) + 4 * u + ps, g.W - 1);
-            const unsigned ot = (x * (unsigned)g.C + (unsigned)c) * 4u;
-            const unsigned og = (x * 2u * (unsigned)g.C + (unsigned)c) * 4u;
-            f.tv[u] = ld_nt4((const float*)(trow + ot));                        // streamed once: keep D / halos cached
-            f.g2[u] = ld_nt4((const float*)(grow + og));
-            f.b2[u] = ld_nt4((const float*)(brow + og));
-            if (HAS_RES) f.rv[u] = *(const float4*)(rrow + ot);
+            const unsigned ot = (x * (unsigned)g.C + (unsigned)c) * (unsigned)sizeof(TA);
+            const unsigned og = (x * 2u * (unsigned)g.C + (unsigned)c) * (unsigned)sizeof(TA);
+            f.tv[u] = ld4_nt((const TA*)(trow + ot));                            // streamed once: keep D / halos cached
+            f.g2[u] = ld4_nt((const TA*)(grow + og));
+            f.b2[u] = ld4_nt((const TA*)(brow + og));
+            if (HAS_RES) f.rv[u] = ld4((const TA*)(rrow + ot));
         }
     };
     Buf fa, fb;
@@ -572,8 +562,8 @@ __global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const fl
                     o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
                 }
                 if (live && y < g.H && x < g.W) {
-                    float* dst = (float*)(orow + ((unsigned)x * (unsigned)g.C + (unsigned)c) * 4u);
-                    st_nt4(dst, o);       // written once, read by the next kernel from HBM: do not displace the inputs
+                    TA* dst = (TA*)(orow + ((unsigned)x * (unsigned)g.C + (unsigned)c) * (unsigned)sizeof(TA));
+                    st4_nt(dst, o);       // written once, read by the next kernel from HBM: do not displace the inputs
                 }
             }
         };
@@ -612,14 +602,15 @@ __global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const fl
 #define SB_TH 4
 #define SB_GST 144
 
+template <typename T>
 __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
-    SeanGeom g, const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ t,
-    const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gb2,
+    SeanGeom g, const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ t,
+    const float* __restrict__ mean, const float* __restrict__ var, const T* __restrict__ gb2,
     const unsigned char* __restrict__ region, const int* __restrict__ flag, const float* __restrict__ D,
     const float* __restrict__ bias_g, const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
-    const float* __restrict__ alpha_b, float* __restrict__ dt, float* __restrict__ dgb2, float* __restrict__ dD_slabs,
+    const float* __restrict__ alpha_b, T* __restrict__ dt, T* __restrict__ dgb2, float* __restrict__ dD_slabs,
     float* __restrict__ dbias_g, float* __restrict__ dbias_b, float* __restrict__ dalpha_g,
-    float* __restrict__ dalpha_b, float* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
+    float* __restrict__ dalpha_b, T* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
     if (flag && *flag != 0) return;
     DASR_DYN_SMEM(smem);
     const int K1 = g.K + 1;
@@ -667,25 +658,25 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
                 float4 G1 = zero4, B1 = zero4;
                 if (live && y < g.H && x < g.W) {
                     const size_t p = ((size_t)b * g.H + y) * g.W + x;
-                    float4 g0 = *(const float4*)(dout + p * g.C + c);
+                    float4 g0 = ld4(dout + p * g.C + c);
                     if (relu) {
-                        const float4 ov = *(const float4*)(out + p * g.C + c);
+                        const float4 ov = ld4(out + p * g.C + c);
                         g0.x = ov.x > 0.f ? g0.x : 0.f; g0.y = ov.y > 0.f ? g0.y : 0.f;
                         g0.z = ov.z > 0.f ? g0.z : 0.f; g0.w = ov.w > 0.f ? g0.w : 0.f;
                     }
-                    if (dres) *(float4*)(dres + p * g.C + c) = g0;
-                    const float4 tv = *(const float4*)(t + p * g.C + c);
-                    const float4 g2 = *(const float4*)(gb2 + p * 2 * g.C + c);
-                    const float4 b2 = *(const float4*)(gb2 + p * 2 * g.C + g.C + c);
+                    if (dres) st4(dres + p * g.C + c, g0);
+                    const float4 tv = ld4(t + p * g.C + c);
+                    const float4 g2 = ld4(gb2 + p * 2 * g.C + c);
+                    const float4 b2 = ld4(gb2 + p * 2 * g.C + g.C + c);
                     float4 g1, b1;
                     sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
                     const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
                     const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
                     const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
-                    *(float4*)(dgb2 + p * 2 * g.C + c) = make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y,
-                                                                    (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w);
-                    *(float4*)(dgb2 + p * 2 * g.C + g.C + c) = make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y,
-                                                                          (1.f - a_b) * g0.z, (1.f - a_b) * g0.w);
+                    st4(dgb2 + p * 2 * g.C + c, make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y,
+                                                            (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w));
+                    st4(dgb2 + p * 2 * g.C + g.C + c, make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y,
+                                                                  (1.f - a_b) * g0.z, (1.f - a_b) * g0.w));
                     dag += dgam.x * (g1.x - g2.x) + dgam.y * (g1.y - g2.y) + dgam.z * (g1.z - g2.z) +
                            dgam.w * (g1.w - g2.w);
                     dab += g0.x * (b1.x - b2.x) + g0.y * (b1.y - b2.y) + g0.z * (b1.z - b2.z) + g0.w * (b1.w - b2.w);
@@ -698,7 +689,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
                     dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
                     dxh.z = g0.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z);
                     dxh.w = g0.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w);
-                    *(float4*)(dt + p * g.C + c) = dxh;
+                    st4(dt + p * g.C + c, dxh);
                     S1 = f4add(S1, dxh);
                     S2.x = fmaf(dxh.x, xc.x, S2.x); S2.y = fmaf(dxh.y, xc.y, S2.y);
                     S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
@@ -806,10 +797,11 @@ static int sean_bwd_blocks_per_sample(int B, int H, int W) {
     return n;
 }
 
-extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var, const float* gb2, const float* mask,
-                             const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_g,
-                             const float* bias_b, const float* alpha_g, const float* alpha_b, const float* residual,
-                             float* out, int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
+template <typename T>
+static int sean_fwd_impl(const T* t, const float* mean, const float* var, const T* gb2, const float* mask,
+                         const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_g,
+                         const float* bias_b, const float* alpha_g, const float* alpha_b, const T* residual,
+                         T* out, int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
     DASR_CHECK_PTR(t); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var); DASR_CHECK_PTR(gb2); DASR_CHECK_PTR(mask);
     DASR_CHECK_PTR(D); DASR_CHECK_PTR(bias_g); DASR_CHECK_PTR(bias_b); DASR_CHECK_PTR(alpha_g); DASR_CHECK_PTR(alpha_b);
     DASR_CHECK_PTR(out);
@@ -828,7 +820,7 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
         const int per = ((tiles / nwg) << 16) | (tiles % nwg);      // (base, rem), see the kernel; rem < nwg <= 768
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
 #define SEAN_FWD_GO(RELU, RES)                                                                                     \
-    DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES>), dim3(nwg, slices), dim3(256), lds, stream, g, t,                        \
+    DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES, T>), dim3(nwg, slices), dim3(256), lds, stream, g, t,                        \
                 mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, eps, per)
         if (relu) { if (residual) SEAN_FWD_GO(true, true); else SEAN_FWD_GO(true, false); }
         else      { if (residual) SEAN_FWD_GO(false, true); else SEAN_FWD_GO(false, false); }
@@ -837,11 +829,28 @@ extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var
     if (!fast_only) {
         int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
         size_t lds = sizeof(float) * (size_t)(2 * 9 * K * 64 + K * (SEAN_TH + 2) * (SEAN_TW + 2));
-        DASR_LAUNCH(k_sean_fwd, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2, mask, D,
+        DASR_LAUNCH((k_sean_fwd<T>), dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2, mask, D,
                     bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps,
                     fast ? onehot_flag : (const int*)nullptr);
     }
     DASR_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var, const float* gb2, const float* mask,
+                             const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_g,
+                             const float* bias_b, const float* alpha_g, const float* alpha_b, const float* residual,
+                             float* out, int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
+    return sean_fwd_impl<float>(t, mean, var, gb2, mask, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual,
+                                out, relu, B, H, W, C, K, eps, stream);
+}
+extern "C" int dasr_sean_fwd_bf16(const unsigned short* t, const float* mean, const float* var, const unsigned short* gb2,
+                                  const float* mask, const unsigned char* region, const int* onehot_flag, const float* D,
+                                  const float* bias_g, const float* bias_b, const float* alpha_g, const float* alpha_b,
+                                  const unsigned short* residual, unsigned short* out, int relu, int B, int H, int W, int C,
+                                  int K, float eps, void* stream) {
+    return sean_fwd_impl<bf16_t>((const bf16_t*)t, mean, var, (const bf16_t*)gb2, mask, region, onehot_flag, D, bias_g,
+                                 bias_b, alpha_g, alpha_b, (const bf16_t*)residual, (bf16_t*)out, relu, B, H, W, C, K, eps,
+                                 stream);
 }
 
 __global__ void __launch_bounds__(256) k_sean_bwd_zero(float* __restrict__ S, int nS, float* __restrict__ dbg,
@@ -855,6 +864,18 @@ __global__ void __launch_bounds__(256) k_sean_bwd_zero(float* __restrict__ S, in
     else if (i == nS + 2 * C + 1) dab[0] = 0.f;
 }
 
+// LDS bytes of the general (soft-mask) backward kernel: D tables + mask tile + dD accumulators + reduction scratch
+static size_t sean_bwd_general_lds(int K) {
+    return sizeof(float) * (size_t)(2 * (2 * 9 * K * 64) + K * (SEAN_TH + 2) * (SEAN_TW + 2) + 6 * 256);
+}
+// Largest region count the soft-mask kernels take forward AND backward (the backward keeps two [2][9][K][64] tables in
+// the CU's 160 KB of LDS: K <= 14); one-hot masks go up to SEAN_MAXK = 16.
+extern "C" int dasr_sean_soft_mask_max_regions(void) {
+    int k = SEAN_MAXK;
+    while (k > 1 && sean_bwd_general_lds(k) > 160 * 1024) --k;
+    return k;
+}
+
 extern "C" size_t dasr_sean_bwd_workspace(int B, int H, int W, int C, int K) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
     size_t S = 2 * (size_t)B * C;
@@ -862,12 +883,13 @@ extern "C" size_t dasr_sean_bwd_workspace(int B, int H, int W, int C, int K) {
     return sizeof(float) * (S + slabs);
 }
 
-extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t, const float* mean, const float* var,
-                             const float* gb2, const float* mask, const unsigned char* region, const int* onehot_flag,
-                             const float* D, const float* bias_g, const float* bias_b, const float* alpha_g,
-                             const float* alpha_b, float* dt, float* dgb2, float* dD, float* dbias_g, float* dbias_b,
-                             float* dalpha_g, float* dalpha_b, float* dres, void* workspace, size_t workspace_bytes,
-                             int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
+template <typename T>
+static int sean_bwd_impl(const T* dout, const T* out, const T* t, const float* mean, const float* var,
+                         const T* gb2, const float* mask, const unsigned char* region, const int* onehot_flag,
+                         const float* D, const float* bias_g, const float* bias_b, const float* alpha_g,
+                         const float* alpha_b, T* dt, T* dgb2, float* dD, float* dbias_g, float* dbias_b,
+                         float* dalpha_g, float* dalpha_b, T* dres, void* workspace, size_t workspace_bytes,
+                         int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
     DASR_CHECK_PTR(dout); DASR_CHECK_PTR(out); DASR_CHECK_PTR(t); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var);
     DASR_CHECK_PTR(gb2); DASR_CHECK_PTR(mask); DASR_CHECK_PTR(D); DASR_CHECK_PTR(bias_g); DASR_CHECK_PTR(bias_b);
     DASR_CHECK_PTR(alpha_g); DASR_CHECK_PTR(alpha_b); DASR_CHECK_PTR(dt); DASR_CHECK_PTR(dgb2); DASR_CHECK_PTR(dD);
@@ -883,6 +905,7 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
     float* slabs = S + 2 * (size_t)B * C;
     const bool fast = region != nullptr && (C % 4) == 0;
     const bool fast_only = fast && onehot_flag == nullptr;
+    if (!fast_only && K > dasr_sean_soft_mask_max_regions()) return DASR_E_UNSUPPORTED;
     // the accumulators the kernels add into with atomics: one launch instead of five memsets; dD is only accumulated
     // into by the general kernel (the one-hot path overwrites all of it in k_sean_dD_reduce)
     (void)st;
@@ -897,7 +920,7 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
         int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SB_TH - 1) / SB_TH);
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64 + SB_TH * SF_TW * SB_GST + 8 * 18 * 16) +
                      (SB_TH + 2) * (SF_TW + 2);
-        DASR_LAUNCH(k_sean_bwd_a_onehot, dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t, mean,
+        DASR_LAUNCH((k_sean_bwd_a_onehot<T>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t, mean,
                     var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
                     dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
         size_t n = (size_t)B * 18 * K * C;
@@ -906,8 +929,8 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
     }
     if (!fast_only) {
         int tiles = ((W + SEAN_TW - 1) / SEAN_TW) * ((H + SEAN_TH - 1) / SEAN_TH);
-        size_t lds = sizeof(float) * (size_t)(2 * (2 * 9 * K * 64) + K * (SEAN_TH + 2) * (SEAN_TW + 2) + 6 * 256);
-        DASR_LAUNCH(k_sean_bwd_a, dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, dout, out, t, mean, var,
+        size_t lds = sean_bwd_general_lds(K);
+        DASR_LAUNCH((k_sean_bwd_a<T>), dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, dout, out, t, mean, var,
                     gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, dD, dbias_g, dbias_b, dalpha_g, dalpha_b,
                     dres, S, relu, eps, fast ? onehot_flag : (const int*)nullptr);
     }
@@ -916,10 +939,33 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
         const int npl = 256 / (C / 4);
         unsigned gx = dasr_cdiv((size_t)H * W, npl * 8);     // eight pixels per thread
         if (gx < 1) gx = 1;
-        DASR_LAUNCH(k_sean_bwd_b_rows, dim3(gx, B), dim3(256), 0, stream, t, mean, var, S, dt, H * W, C, eps);
+        DASR_LAUNCH((k_sean_bwd_b_rows<T>), dim3(gx, B), dim3(256), 0, stream, t, mean, var, S, dt, H * W, C, eps);
     } else {
-        DASR_LAUNCH(k_sean_bwd_b, dim3(dasr_ew_grid((C & 3) == 0 ? n / 4 : n)), dim3(256), 0, stream, t, mean, var, S,
+        DASR_LAUNCH((k_sean_bwd_b<T>), dim3(dasr_ew_grid((C & 3) == 0 ? n / 4 : n)), dim3(256), 0, stream, t, mean, var, S,
                     dt, H * W, C, n, eps);
     }
     DASR_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t, const float* mean, const float* var,
+                             const float* gb2, const float* mask, const unsigned char* region, const int* onehot_flag,
+                             const float* D, const float* bias_g, const float* bias_b, const float* alpha_g,
+                             const float* alpha_b, float* dt, float* dgb2, float* dD, float* dbias_g, float* dbias_b,
+                             float* dalpha_g, float* dalpha_b, float* dres, void* workspace, size_t workspace_bytes,
+                             int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
+    return sean_bwd_impl<float>(dout, out, t, mean, var, gb2, mask, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b,
+                                dt, dgb2, dD, dbias_g, dbias_b, dalpha_g, dalpha_b, dres, workspace, workspace_bytes, relu, B,
+                                H, W, C, K, eps, stream);
+}
+extern "C" int dasr_sean_bwd_bf16(const unsigned short* dout, const unsigned short* out, const unsigned short* t,
+                                  const float* mean, const float* var, const unsigned short* gb2, const float* mask,
+                                  const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_g,
+                                  const float* bias_b, const float* alpha_g, const float* alpha_b, unsigned short* dt,
+                                  unsigned short* dgb2, float* dD, float* dbias_g, float* dbias_b, float* dalpha_g,
+                                  float* dalpha_b, unsigned short* dres, void* workspace, size_t workspace_bytes, int relu,
+                                  int B, int H, int W, int C, int K, float eps, void* stream) {
+    return sean_bwd_impl<bf16_t>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)t, mean, var, (const bf16_t*)gb2,
+                                 mask, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, (bf16_t*)dt, (bf16_t*)dgb2, dD,
+                                 dbias_g, dbias_b, dalpha_g, dalpha_b, (bf16_t*)dres, workspace, workspace_bytes, relu, B, H, W,
+                                 C, K, eps, stream);
 }

@@ -3,6 +3,7 @@
 // dims but 0; for ConvTranspose2d dim 0 is the in-channel axis).  Tiny tensors: one workgroup per norm
 // group, wave shuffles + LDS for the reduction.
 #include "dasr_common.h"
+#include "bf16.h"
 
 __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -23,8 +24,11 @@ __device__ __forceinline__ size_t hwio_index(int n, int r, int ldo, int o_off, i
     return ((size_t)t * I + i) * ldo + o_off + o;
 }
 
+// TW = element type of the packed kernel: float, or bf16_t for the bf16 trunk convolutions (fp32 master weights, the
+// normalisation is done in fp32 and rounded once)
+template <typename TW>
 __global__ void __launch_bounds__(256) k_weight_pack_fwd(const float* __restrict__ v, const float* __restrict__ g,
-                                                         float* __restrict__ w, float* __restrict__ inv_norm, int O,
+                                                         TW* __restrict__ w, float* __restrict__ inv_norm, int O,
                                                          int I, int KK, int transposed, int ldo, int o_off) {
     __shared__ float red[4];
     int n = blockIdx.x;
@@ -40,13 +44,13 @@ __global__ void __launch_bounds__(256) k_weight_pack_fwd(const float* __restrict
         scale = g[n] * inv;
     }
     // second half of the packed buffer: the same kernel with each tap transposed, [tap][ldo][I]
-    float* wT = w + (size_t)KK * I * ldo;
+    TW* wT = w + (size_t)KK * I * ldo;
     for (int r = threadIdx.x; r < R; r += 256) {
         const float val = vn[r] * scale;
-        w[hwio_index(n, r, ldo, o_off, I, KK, transposed)] = val;
+        st1(w + hwio_index(n, r, ldo, o_off, I, KK, transposed), val);
         int a = r / KK, t = r % KK;
         int o = transposed ? a : n, i = transposed ? n : a;
-        wT[((size_t)t * ldo + o_off + o) * I + i] = val;
+        st1(wT + ((size_t)t * ldo + o_off + o) * I + i, val);
     }
 }
 
@@ -81,8 +85,18 @@ extern "C" int dasr_weight_pack_fwd(const float* v, const float* g, float* w, fl
     if (g) DASR_CHECK_PTR(inv_norm);
     DASR_CHECK_SHAPE(O > 0 && I > 0 && KH > 0 && KW > 0 && o_off >= 0 && ldo >= o_off + O);
     int groups = transposed ? I : O;
-    DASR_LAUNCH(k_weight_pack_fwd, dim3(groups), dim3(256), 0, stream, v, g, w, inv_norm, O, I, KH * KW, transposed, ldo,
-                o_off);
+    DASR_LAUNCH((k_weight_pack_fwd<float>), dim3(groups), dim3(256), 0, stream, v, g, w, inv_norm, O, I, KH * KW, transposed,
+                ldo, o_off);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+extern "C" int dasr_weight_pack_fwd_bf16(const float* v, const float* g, unsigned short* w, float* inv_norm, int O, int I,
+                                         int KH, int KW, int transposed, int ldo, int o_off, void* stream) {
+    DASR_CHECK_PTR(v); DASR_CHECK_PTR(w);
+    if (g) DASR_CHECK_PTR(inv_norm);
+    DASR_CHECK_SHAPE(O > 0 && I > 0 && KH > 0 && KW > 0 && o_off >= 0 && ldo >= o_off + O);
+    int groups = transposed ? I : O;
+    DASR_LAUNCH((k_weight_pack_fwd<bf16_t>), dim3(groups), dim3(256), 0, stream, v, g, (bf16_t*)w, inv_norm, O, I, KH * KW,
+                transposed, ldo, o_off);
     DASR_RETURN_LAUNCH_STATUS();
 }
 extern "C" int dasr_weight_pack_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, float* dv,

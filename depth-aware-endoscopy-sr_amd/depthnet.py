@@ -138,8 +138,8 @@ def _device_guard(t):
 
 class _DepthNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, inp, depth_map, depth_mask, region, *params):
-        tape = Tape(enabled=True)
+    def forward(ctx, net, act_dtype, inp, depth_map, depth_mask, region, *params):
+        tape = Tape(enabled=True, act_dtype=act_dtype)
         pvars = [Var(p.detach(), p.requires_grad, name) for name, p in zip(net._param_names, params)]
         P = {v.name: v for v in pvars}
         out = graph.depthnet_forward(tape, P, net.cfg, net._consts(inp.device), inp.detach().contiguous(),
@@ -161,7 +161,7 @@ class _DepthNetFunction(torch.autograd.Function):
         for v in pvars:
             v.grad = None
         ctx.tape = ctx.pvars = ctx.out = None
-        return (None, None, None, None, None) + grads
+        return (None, None, None, None, None, None) + grads
 
 
 class DepthNet(nn.Module):
@@ -209,6 +209,28 @@ class DepthNet(nn.Module):
         # plain attributes and exposes no parameters at all (torch >= 1.5, torch/nn/parallel/replicate.py).
         self._param_names = tuple(name for name, _ in self.named_parameters())
         self._param_paths = tuple(tuple(name.split(".")) for name in self._param_names)
+        self.compute_dtype = torch.float32
+
+    def set_compute_dtype(self, dtype):
+        """Storage type of the trunk's activations: ``torch.float32`` (default, the reference's precision) or
+        ``torch.bfloat16`` (BASELINE.json configs[2..3]: bf16 activations and bf16-MFMA trunk convolutions; parameters,
+        their gradients, instance-norm statistics, the dynamic kernels and every accumulator stay fp32; inputs and the
+        returned image are fp32).  Never switched silently: either this call, or the caller's own
+        ``torch.autocast('cuda', dtype=torch.bfloat16)`` around ``forward`` - the way a reference checkout opts in."""
+        if isinstance(dtype, str):
+            dtype = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                     "bfloat16": torch.bfloat16}[dtype]
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("DepthNet: compute dtype must be float32 or bfloat16")
+        self.compute_dtype = dtype
+        return self
+
+    def _act_dtype(self, device):
+        if self.compute_dtype == torch.bfloat16:
+            return torch.bfloat16
+        if device.type == "cuda" and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+            return torch.bfloat16
+        return torch.float32
 
     # constants used when the blend weights are not trainable (normalization.py:33-35)
     def _consts(self, device):
@@ -249,9 +271,10 @@ class DepthNet(nn.Module):
         # masks prepared on the device (dasr_amd.prep.depth_to_masks) carry their region bytes: no compression pass,
         # no host read-back of the one-hot flag
         region = graph.attached_region(depthMask)
+        act_dtype = self._act_dtype(input.device)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _DepthNetFunction.apply(self, input, depthMap, depthMask, region, *params)
-        tape = Tape(enabled=False)
+            return _DepthNetFunction.apply(self, act_dtype, input, depthMap, depthMask, region, *params)
+        tape = Tape(enabled=False, act_dtype=act_dtype)
         if not self.training:                 # netG.eval() + no_grad (F_model_depthCond.test): fold weights once
             if not hasattr(self, "_fold_cache"):
                 object.__setattr__(self, "_fold_cache", {})

@@ -28,18 +28,21 @@ SIDE_STREAM = True
 # Weight / bias gradients are off the critical path of the backward (nothing but the optimiser waits for them): they
 # run on a third stream and fill whatever the data-gradient chain leaves idle.
 import os as _os
+import threading as _threading
 TAIL_WGRAD_SIDE = False  # weight gradients of the HR tail on the (then idle) depth-branch stream; see conv(side_wgrad=)
 FUSE_INSTNORM_STATS = False  # measured: 115.5 -> 111.5 frames/s when on (two more barriers + reductions in the 64->64 conv epilogue cost more than the statistics pass they replace); the entry point stays, tested
 WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
+_SIDE_LOCK = _threading.Lock()
 
 
 def _side_stream(device, which="branch"):
     key = (str(device), which)
-    if key not in _SIDE:
-        # high priority: the depth branch is the longer of the two chains in both directions (measured +0.8 %)
-        _SIDE[key] = torch.cuda.Stream(device=device, priority=-1)
-    return _SIDE[key]
+    with _SIDE_LOCK:                      # nn.DataParallel calls forward from one thread per replica
+        if key not in _SIDE:
+            # high priority: the depth branch is the longer of the two chains in both directions (measured +0.8 %)
+            _SIDE[key] = torch.cuda.Stream(device=device, priority=-1)
+        return _SIDE[key]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -62,11 +65,12 @@ def _folded(tape, key, tensors, make):
     return val
 
 
-def pack(tape, v, g=None, transposed=False):
-    """weight_norm (if g) + OIHW -> HWIO."""
+def pack(tape, v, g=None, transposed=False, dtype=torch.float32):
+    """weight_norm (if g) + OIHW -> HWIO; ``dtype`` bf16 for the trunk kernels of the mixed-precision path (fp32 master
+    weights: the packed copy is rounded, the gradient comes back in fp32)."""
     srcs = [v.data] + ([g.data] if g is not None else [])
-    w, inv = _folded(tape, ("pack", v.name) if v.name else None, srcs,
-                     lambda: ops.weight_pack(v.data, g.data if g is not None else None, transposed))
+    w, inv = _folded(tape, ("pack", v.name, str(dtype)) if v.name else None, srcs,
+                     lambda: ops.weight_pack(v.data, g.data if g is not None else None, transposed, dtype=dtype))
     out = Var(w, v.requires_grad or (g is not None and g.requires_grad))
 
     def bwd():
@@ -85,18 +89,18 @@ def pack(tape, v, g=None, transposed=False):
     return out
 
 
-def pack_pair(tape, va, vb):
+def pack_pair(tape, va, vb, dtype=torch.float32):
     """Two plain OIHW kernels with equal Cin side by side along Cout (mlp_gamma_o | mlp_beta_o)."""
     Oa, I, KH, KW = va.data.shape
     Ob = vb.data.shape[0]
 
     def make():
-        w = ops.empty((2, KH, KW, I, Oa + Ob), va.data)
+        w = ops.empty((2, KH, KW, I, Oa + Ob), va.data, dtype)
         ops.weight_pack(va.data, None, False, out=w, o_off=0)
         ops.weight_pack(vb.data, None, False, out=w, o_off=Oa)
         return w
 
-    w = _folded(tape, ("pair", va.name) if va.name else None, [va.data, vb.data], make)
+    w = _folded(tape, ("pair", va.name, str(dtype)) if va.name else None, [va.data, vb.data], make)
     out = Var(w, va.requires_grad or vb.requires_grad)
 
     def bwd():
@@ -143,16 +147,17 @@ def bias_pair(tape, ba, bb):
 
 
 def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.ACT_NONE, ps_r=1, residual=None,
-         side_wgrad=False, want_stats=False):
+         side_wgrad=False, want_stats=False, out_dtype=None):
     stats = None
-    if (want_stats and FUSE_INSTNORM_STATS and act == ops.ACT_NONE and ps_r == 1 and residual is None and stride == 1 and
-            pad == 1 and not transposed and tuple(w.data.shape[1:3]) == (3, 3)):
+    f32 = x.data.dtype == torch.float32 and out_dtype in (None, torch.float32)
+    if (want_stats and FUSE_INSTNORM_STATS and f32 and act == ops.ACT_NONE and ps_r == 1 and residual is None and
+            stride == 1 and pad == 1 and not transposed and tuple(w.data.shape[1:3]) == (3, 3)):
         # the InstanceNorm statistics of the output come out of the convolution's epilogue (no second pass over y)
         y, mean, var = ops.conv2d_fwd_stats(x.data, w.data, bias.data if bias is not None else None)
         stats = (mean, var)
     else:
         y = ops.conv2d_fwd(x.data, w.data, bias.data if bias is not None else None,
-                           residual.data if residual is not None else None, stride, pad, transposed, act, ps_r)
+                           residual.data if residual is not None else None, stride, pad, transposed, act, ps_r, out_dtype)
     needs = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad) or \
         (residual is not None and residual.requires_grad)
     out = Var(y, needs)
@@ -213,7 +218,7 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             if bias is not None:
                 accum(bias, db)
         if x.requires_grad:
-            if (FUSE_DGRAD_ACT and x.grad is None and x.uses == 1 and x.epilogue is not None and
+            if (FUSE_DGRAD_ACT and f32 and x.grad is None and x.uses == 1 and x.epilogue is not None and
                     ops.conv2d_dgrad_act_supported(x.data.shape, w.data, dconv.shape, stride, pad, transposed,
                                                    x.epilogue[1])):
                 # x = PixelShuffle(act(prev conv)) and this conv is its only consumer: write d(prev conv output)
@@ -221,11 +226,32 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
                                               transposed)
                 x.grad_is_preact = True
             elif x.grad is None:
-                x.grad = ops.conv2d_dgrad(dconv, w.data, x.data.shape, stride, pad, transposed)
+                x.grad = ops.conv2d_dgrad(dconv, w.data, x.data.shape, stride, pad, transposed, out_dtype=x.data.dtype)
             else:
                 ops.conv2d_dgrad(dconv, w.data, x.data.shape, stride, pad, transposed, out=x.grad)
         if residual is not None:
             accum(residual, dconv)
+
+    tape.record(bwd)
+    return out
+
+
+def to_bf16(tape, x):
+    """fp32 encoder -> bf16 trunk boundary (the encoder's first feature map feeds the head): one rounding forward, the
+    bf16 gradient is added into the fp32 gradient of the source on the way back."""
+    x.uses += 1
+    out = Var(ops.cast_to_bf16(x.data), x.requires_grad)
+
+    def bwd():
+        if out.grad is None:
+            return
+        g = out.grad
+        out.grad = None
+        if x.requires_grad:
+            if x.grad is None:
+                x.grad = ops.cast_to_f32(g)
+            else:
+                ops.accumulate_(x.grad, g)
 
     tape.record(bwd)
     return out
@@ -356,6 +382,13 @@ class MaskPack:
             self.region, self.flag = region, flag
             return
         self.region, self.flag = ops.mask_compress(planes)
+        if planes.shape[1] > ops.soft_mask_max_regions():
+            # more regions than the soft-mask kernels hold in LDS (K = 15, 16): the device cannot fall back to them, so
+            # the flag has to be known here - the one place the host still reads it
+            if int(self.flag.item()) != 0:
+                raise NotImplementedError("dasr_amd: soft (non one-hot) masks are supported for up to %d regions, got %d"
+                                          % (ops.soft_mask_max_regions(), planes.shape[1]))
+            self.flag = None
 
     def resized(self, H, W):
         """F.interpolate(mask, mode='nearest') at a block's feature size (normalization.py:59), once per size per
@@ -381,8 +414,8 @@ class MaskPack:
 # ---------------------------------------------------------------------------------------------
 # blocks
 # ---------------------------------------------------------------------------------------------
-def _wn(tape, P, prefix, transposed=False):
-    return pack(tape, P[prefix + ".weight_v"], P[prefix + ".weight_g"], transposed)
+def _wn(tape, P, prefix, transposed=False, dtype=torch.float32):
+    return pack(tape, P[prefix + ".weight_v"], P[prefix + ".weight_g"], transposed, dtype)
 
 
 def block_plan(cfg):
@@ -400,9 +433,10 @@ def block_plan(cfg):
 def sean_depth_branch(tape, P, pre, depth_map):
     """gamma2 | beta2 of one SEAN (normalization.py:61,73-74): a function of the depth map and parameters only, so
     the forward plan may compute it ahead of the trunk, on another stream."""
-    w_m = pack(tape, P[pre + ".mlp_mask.0.weight"])
-    actv = conv(tape, depth_map, w_m, P[pre + ".mlp_mask.0.bias"], act=ops.ACT_RELU)
-    w_gb = pack_pair(tape, P[pre + ".mlp_gamma_o.weight"], P[pre + ".mlp_beta_o.weight"])
+    dt = tape.act_dtype
+    w_m = pack(tape, P[pre + ".mlp_mask.0.weight"])                # the depth map stays fp32: fp32 kernel, dt output
+    actv = conv(tape, depth_map, w_m, P[pre + ".mlp_mask.0.bias"], act=ops.ACT_RELU, out_dtype=dt)
+    w_gb = pack_pair(tape, P[pre + ".mlp_gamma_o.weight"], P[pre + ".mlp_beta_o.weight"], dt)
     b_gb = bias_pair(tape, P[pre + ".mlp_gamma_o.bias"], P[pre + ".mlp_beta_o.bias"])
     return conv(tape, actv, w_gb, b_gb)
 
@@ -443,24 +477,29 @@ def depth_block(tape, P, name, x, depth_map, mask, st, consts, gb2_pair=None):
     B, H, W, C = x.data.shape
     depth_map, mask = block_depth_inputs((H, W), depth_map, mask)
     g1, g2 = gb2_pair if gb2_pair is not None else (None, None)
-    t1 = conv(tape, x, pack(tape, P[name + ".conv1.0.weight"]), P[name + ".conv1.0.bias"], want_stats=True)
+    dt = tape.act_dtype
+    t1 = conv(tape, x, pack(tape, P[name + ".conv1.0.weight"], dtype=dt), P[name + ".conv1.0.bias"], want_stats=True)
     a = sean(tape, P, name + ".norm1", t1, depth_map, mask, st, None, True, consts, g1)
-    t2 = conv(tape, a, pack(tape, P[name + ".conv2.0.weight"]), P[name + ".conv2.0.bias"], want_stats=True)
+    t2 = conv(tape, a, pack(tape, P[name + ".conv2.0.weight"], dtype=dt), P[name + ".conv2.0.bias"], want_stats=True)
     return sean(tape, P, name + ".norm2", t2, depth_map, mask, st, x, True, consts, g2)
 
 
 def classic_block(tape, P, name, x):
     """Classic_Residual_Block.forward (sftmd_arch.py:147-151)."""
-    h = conv(tape, x, _wn(tape, P, name + ".block.0"), P[name + ".block.0.bias"], act=ops.ACT_RELU, side_wgrad=True)
-    return conv(tape, h, _wn(tape, P, name + ".block.2"), P[name + ".block.2.bias"], act=ops.ACT_RELU, residual=x,
-                side_wgrad=True)
+    dt = tape.act_dtype
+    h = conv(tape, x, _wn(tape, P, name + ".block.0", dtype=dt), P[name + ".block.0.bias"], act=ops.ACT_RELU,
+             side_wgrad=True)
+    return conv(tape, h, _wn(tape, P, name + ".block.2", dtype=dt), P[name + ".block.2.bias"], act=ops.ACT_RELU,
+                residual=x, side_wgrad=True)
 
 
 def upscale(tape, P, name, x, r, second):
     """upscale1/2/3 (sftmd_arch.py:891-908): conv -> PixelShuffle(r) -> LeakyReLU [-> conv -> LeakyReLU]."""
-    x = conv(tape, x, _wn(tape, P, name + ".0"), P[name + ".0.bias"], act=ops.ACT_LRELU, ps_r=r, side_wgrad=True)
+    dt = tape.act_dtype
+    x = conv(tape, x, _wn(tape, P, name + ".0", dtype=dt), P[name + ".0.bias"], act=ops.ACT_LRELU, ps_r=r,
+             side_wgrad=True)
     if second:
-        x = conv(tape, x, _wn(tape, P, name + ".3"), P[name + ".3.bias"], act=ops.ACT_LRELU, side_wgrad=True)
+        x = conv(tape, x, _wn(tape, P, name + ".3", dtype=dt), P[name + ".3.bias"], act=ops.ACT_LRELU, side_wgrad=True)
     return x
 
 
@@ -485,9 +524,12 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=No
         e5 = conv(tape, e4, _wn(tape, P, "encoder.layer5"), P["encoder.layer5.bias"], stride=2)
         st = region_pool(tape, e5, depth_mask)
     mask_pack = MaskPack(depth_mask, region) if st is not None else None
-    # head (:920)
-    h1 = conv(tape, e1, _wn(tape, P, "head.0"), P["head.0.bias"], act=L)
-    fea_bef = conv(tape, h1, _wn(tape, P, "head.2"), P["head.2.bias"], act=L)
+    # head (:920).  Mixed precision: the encoder (0.8 % of the FLOPs, feeds the fp32 depth matrix) stays fp32; its first
+    # feature map is rounded to bf16 here and everything up to conv_output's fp32 result runs on bf16 activations
+    adt = tape.act_dtype
+    e1h = to_bf16(tape, e1) if adt == torch.bfloat16 else e1
+    h1 = conv(tape, e1h, _wn(tape, P, "head.0", dtype=adt), P["head.0.bias"], act=L)
+    fea_bef = conv(tape, h1, _wn(tape, P, "head.2", dtype=adt), P["head.2.bias"], act=L)
 
     # The depth-map branch of every SEAN (mlp_mask -> ReLU -> gamma_o|beta_o, 55 % of the forward FLOPs) depends on
     # the depth map and parameters only: it is issued on a side HIP stream ahead of the trunk, and its backward runs

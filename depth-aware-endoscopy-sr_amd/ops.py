@@ -1,8 +1,10 @@
 """Tensor-level wrappers of the C ABI (include/dasr.h).
 
 PyTorch is used here for device memory (``torch.empty``) and the current stream only; every
-computation is a call into libdasr_hip.so.  Activations are NHWC ``[B,H,W,C]`` fp32, kernels
-are HWIO ``[KH,KW,Cin,Cout]``.
+computation is a call into libdasr_hip.so.  Activations are NHWC ``[B,H,W,C]``, kernels are HWIO
+``[KH,KW,Cin,Cout]``.  fp32 is the default; a bf16 activation tensor selects the ``*_bf16`` entry
+points (mixed-precision path: bf16 activations and trunk kernels, fp32 parameters / statistics /
+accumulators) - the dtype of the tensors passed in decides, nothing is converted silently.
 """
 import torch
 
@@ -12,8 +14,26 @@ ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 IN_EPS = 1e-5  # nn.InstanceNorm2d default eps (sftmd_arch.py:813, normalization.py:17)
 
 
+BF16 = torch.bfloat16
+
+
 def _p(t, allow_none=False):
     return _lib.ptr(t, allow_none)
+
+
+def _pa(t, allow_none=False):
+    """Pointer of an activation tensor: float32 or bfloat16."""
+    if t is None:
+        return _lib.ptr(t, allow_none)
+    return _lib.ptr(t, allow_none, dtype=t.dtype if t.dtype in (torch.float32, BF16) else torch.float32)
+
+
+def _is_bf(*ts):
+    """True when the tensors that are given are bfloat16 (mixing is a caller bug)."""
+    kinds = {t.dtype for t in ts if t is not None}
+    if len(kinds) > 1:
+        raise TypeError("dasr_amd: mixed activation dtypes %s" % sorted(str(k) for k in kinds))
+    return kinds == {BF16}
 
 
 def _call(name, *args):
@@ -21,8 +41,8 @@ def _call(name, *args):
     _lib.check(fn(*args, _lib.stream()), name)
 
 
-def empty(shape, like):
-    return torch.empty(shape, dtype=torch.float32, device=like.device)
+def empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
 
 
 # ---- edge ----------------------------------------------------------------------------------
@@ -74,20 +94,44 @@ def resize_nearest_u8(region, H, W):
 
 def add(a, b):
     out = torch.empty_like(a)
-    _call("dasr_add", _p(a), _p(b), _p(out), a.numel())
+    if _is_bf(a, b):
+        _call("dasr_add_bf16", _pa(a), _pa(b), _pa(out), a.numel())
+    else:
+        _call("dasr_add", _p(a), _p(b), _p(out), a.numel())
     return out
 
 
 def accumulate_(dst, src):
     assert dst.shape == src.shape
-    _call("dasr_accumulate", _p(dst), _p(src), dst.numel())
+    if dst.dtype == torch.float32 and src.dtype == BF16:       # bf16 gradient arriving at an fp32 tensor
+        _call("dasr_cast_bf16_to_f32", _pa(src), _p(dst), 1, dst.numel())
+    elif _is_bf(dst, src):
+        _call("dasr_accumulate_bf16", _pa(dst), _pa(src), dst.numel())
+    else:
+        _call("dasr_accumulate", _p(dst), _p(src), dst.numel())
     return dst
 
 
 def copy_(dst, src):
-    assert dst.numel() == src.numel()
-    _call("dasr_copy", _p(dst), _p(src), dst.numel())
+    assert dst.numel() == src.numel() and dst.dtype == src.dtype
+    if dst.dtype == BF16:
+        assert dst.numel() % 2 == 0
+        _call("dasr_copy", _pa(dst), _pa(src), dst.numel() // 2)      # a byte copy: two bf16 per float
+    else:
+        _call("dasr_copy", _p(dst), _p(src), dst.numel())
     return dst
+
+
+def cast_to_bf16(x):
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _call("dasr_cast_f32_to_bf16", _p(x), _pa(out), x.numel())
+    return out
+
+
+def cast_to_f32(x):
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _call("dasr_cast_bf16_to_f32", _pa(x), _p(out), 0, x.numel())
+    return out
 
 
 def zeros(shape, like):
@@ -95,18 +139,22 @@ def zeros(shape, like):
 
 
 # ---- weights ------------------------------------------------------------------------------
-def weight_pack(v, g, transposed=False, out=None, o_off=0):
-    """Pack a PyTorch-layout kernel (optionally weight-normed) into HWIO. Returns (w_hwio, inv_norm)."""
+def weight_pack(v, g, transposed=False, out=None, o_off=0, dtype=torch.float32):
+    """Pack a PyTorch-layout fp32 kernel (optionally weight-normed) into HWIO, fp32 or bf16.  Returns (w, inv_norm)."""
     if transposed:
         I, O, KH, KW = v.shape
     else:
         O, I, KH, KW = v.shape
     if out is None:
-        out = empty((2, KH, KW, I, O), v)          # [0]: HWIO, [1]: memory holds the per-tap transpose [KH,KW,O,I]
+        out = empty((2, KH, KW, I, O), v, dtype)   # [0]: HWIO, [1]: memory holds the per-tap transpose [KH,KW,O,I]
     ldo = out.shape[4]
     inv = empty((I if transposed else O,), v) if g is not None else None
-    _call("dasr_weight_pack_fwd", _p(v), _p(g, True), _p(out), _p(inv, True), O, I, KH, KW, int(transposed), ldo,
-          int(o_off))
+    if out.dtype == BF16:
+        _call("dasr_weight_pack_fwd_bf16", _p(v), _p(g, True), _pa(out), _p(inv, True), O, I, KH, KW, int(transposed), ldo,
+              int(o_off))
+    else:
+        _call("dasr_weight_pack_fwd", _p(v), _p(g, True), _p(out), _p(inv, True), O, I, KH, KW, int(transposed), ldo,
+              int(o_off))
     return out, inv
 
 
@@ -134,7 +182,7 @@ def pack_hwio(w4):
     """Packed kernel (HWIO + per-tap transpose) from a plain HWIO tensor - for tests and micro-benchmarks; the
     product path gets packed kernels from weight_pack (dasr_weight_pack_fwd)."""
     KH, KW, I, O = w4.shape
-    out = torch.empty((2, KH, KW, I, O), dtype=w4.dtype, device=w4.device)
+    out = torch.empty((2, KH, KW, I, O), dtype=w4.dtype, device=w4.device)      # bf16 in, bf16 packed
     out[0].copy_(w4)
     out[1].view(KH, KW, O, I).copy_(w4.permute(0, 1, 3, 2))
     return out
@@ -146,36 +194,54 @@ def _wdims(w):
     return tuple(w.shape[1:])
 
 
-def conv2d_fwd(x, w, bias=None, residual=None, stride=1, pad=1, transposed=False, act=ACT_NONE, ps_r=1):
+def conv2d_fwd(x, w, bias=None, residual=None, stride=1, pad=1, transposed=False, act=ACT_NONE, ps_r=1, out_dtype=None):
+    """``out_dtype=torch.bfloat16`` with an fp32 ``x`` is the mask layer of the bf16 path (fp32 depth map in, bf16
+    activation out); a bf16 ``x`` selects the bf16 path by itself (the 9x9 output conv then returns fp32)."""
     B, H, W, Cin = x.shape
     KH, KW, wi, Cout = _wdims(w)
     assert wi == Cin, (w.shape, x.shape)
     Ho, Wo = conv_out_hw(H, W, KH, KW, stride, pad, transposed)
+    bf = x.dtype == BF16 or out_dtype == BF16
+    ydt = torch.float32
+    if bf and not (KH == 9 and Cout <= 3):
+        ydt = BF16
     if ps_r > 1:
-        y = empty((B, Ho * ps_r, Wo * ps_r, Cout // (ps_r * ps_r)), x)
+        y = empty((B, Ho * ps_r, Wo * ps_r, Cout // (ps_r * ps_r)), x, ydt)
     else:
-        y = empty((B, Ho, Wo, Cout), x)
-    _call("dasr_conv2d_fwd", _p(x), _p(w), _p(bias, True), _p(residual, True), _p(y), B, H, W, Cin, Ho, Wo, Cout, KH,
-          KW, stride, pad, int(transposed), act, ps_r)
+        y = empty((B, Ho, Wo, Cout), x, ydt)
+    if bf:
+        _call("dasr_conv2d_fwd_bf16", _pa(x), _pa(w), _p(bias, True), _pa(residual, True), _pa(y), B, H, W, Cin, Ho, Wo,
+              Cout, KH, KW, stride, pad, int(transposed), act, ps_r)
+    else:
+        _call("dasr_conv2d_fwd", _p(x), _p(w), _p(bias, True), _p(residual, True), _p(y), B, H, W, Cin, Ho, Wo, Cout, KH,
+              KW, stride, pad, int(transposed), act, ps_r)
     return y
 
 
 def conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r):
     B = y.shape[0]
-    dconv = empty((B, Ho, Wo, Cout), y)
-    _call("dasr_conv2d_epilogue_bwd", _p(dy), _p(y), _p(dconv), B, Ho, Wo, Cout, act, ps_r)
+    dconv = empty((B, Ho, Wo, Cout), y, y.dtype)
+    if _is_bf(dy, y):
+        _call("dasr_conv2d_epilogue_bwd_bf16", _pa(dy), _pa(y), _pa(dconv), B, Ho, Wo, Cout, act, ps_r)
+    else:
+        _call("dasr_conv2d_epilogue_bwd", _p(dy), _p(y), _p(dconv), B, Ho, Wo, Cout, act, ps_r)
     return dconv
 
 
-def conv2d_dgrad(dconv, w, x_shape, stride=1, pad=1, transposed=False, out=None):
+def conv2d_dgrad(dconv, w, x_shape, stride=1, pad=1, transposed=False, out=None, out_dtype=torch.float32):
+    """``out_dtype`` = dtype of the conv's input (bf16 input -> bf16 gradient; the 9x9 output conv takes an fp32 dconv)."""
     B, H, W, Cin = x_shape
     KH, KW, _, Cout = _wdims(w)
     _, Ho, Wo, _ = dconv.shape
     acc = out is not None
     if out is None:
-        out = torch.empty(x_shape, dtype=torch.float32, device=dconv.device)
-    _call("dasr_conv2d_dgrad", _p(dconv), _p(w), _p(out), int(acc), B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad,
-          int(transposed))
+        out = torch.empty(x_shape, dtype=out_dtype, device=dconv.device)
+    if out.dtype == BF16:
+        _call("dasr_conv2d_dgrad_bf16", _pa(dconv), _pa(w), _pa(out), int(acc), B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride,
+              pad, int(transposed))
+    else:
+        _call("dasr_conv2d_dgrad", _p(dconv), _p(w), _p(out), int(acc), B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad,
+              int(transposed))
     return out
 
 
@@ -203,12 +269,18 @@ def conv2d_wgrad(x, dconv, w_shape, stride=1, pad=1, transposed=False, want_bias
     KH, KW, _, Cout = w_shape
     _, Ho, Wo, _ = dconv.shape
     lib = _lib.get()
-    nbytes = lib.dasr_conv2d_wgrad_workspace(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, int(transposed))
+    bf = x.dtype == BF16
+    wsfn = lib.dasr_conv2d_wgrad_workspace_bf16 if bf else lib.dasr_conv2d_wgrad_workspace
+    nbytes = wsfn(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, int(transposed))
     ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
     dw = empty(w_shape, x)
     db = empty((Cout,), x) if want_bias else None
-    _call("dasr_conv2d_wgrad", _p(x), _p(dconv), _p(dw), _p(db, True), _p(ws), nbytes, B, H, W, Cin, Ho, Wo, Cout, KH,
-          KW, stride, pad, int(transposed))
+    if bf:
+        _call("dasr_conv2d_wgrad_bf16", _pa(x), _pa(dconv), _p(dw), _p(db, True), _p(ws), nbytes, B, H, W, Cin, Ho, Wo,
+              Cout, KH, KW, stride, pad, int(transposed))
+    else:
+        _call("dasr_conv2d_wgrad", _p(x), _p(dconv), _p(dw), _p(db, True), _p(ws), nbytes, B, H, W, Cin, Ho, Wo, Cout, KH,
+              KW, stride, pad, int(transposed))
     return dw, db
 
 
@@ -218,6 +290,12 @@ def conv2d_wgrad_act(x, dy, y, w_shape, act, stride=1, pad=1, transposed=False, 
     KH, KW, _, Cout = w_shape
     _, Ho, Wo, _ = y.shape
     lib = _lib.get()
+    if _is_bf(dy, y):                      # the mask layer of the bf16 path: fused kernel only
+        dw = empty(w_shape, x)
+        db = empty((Cout,), x) if want_bias else None
+        _call("dasr_conv2d_wgrad_act_bf16", _p(x), _pa(dy), _pa(y), _p(dw), _p(db, True), B, H, W, Cin, Ho, Wo, Cout, KH, KW,
+              stride, pad, int(transposed), act)
+        return dw, db
     nbytes = lib.dasr_conv2d_wgrad_workspace(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, int(transposed))
     ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
     fused = (Cin == 1 and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not transposed)
@@ -251,7 +329,10 @@ def instnorm_stats(x):
     var = empty((B, C), x)
     nbytes = _lib.get().dasr_instnorm_stats_workspace(B, H * W, C)
     ws = torch.empty((max(1, nbytes // 4),), dtype=torch.float32, device=x.device)
-    _call("dasr_instnorm_stats", _p(x), _p(mean), _p(var), _p(ws), nbytes, B, H * W, C)
+    if x.dtype == BF16:
+        _call("dasr_instnorm_stats_bf16", _pa(x), _p(mean), _p(var), _p(ws), nbytes, B, H * W, C)
+    else:
+        _call("dasr_instnorm_stats", _p(x), _p(mean), _p(var), _p(ws), nbytes, B, H * W, C)
     return mean, var
 
 
@@ -275,6 +356,10 @@ def dynk_bwd(dD, st, stp, A_w, Wg, Wb, dst_accum):
     _call("dasr_dynk_bwd", _p(dD), _p(st), _p(stp), _p(A_w), _p(Wg), _p(Wb), _p(dWg), _p(dWb), _p(dA_w), _p(dA_b),
           _p(dst_accum), _p(scratch), B, K, L, C)
     return dWg, dWb, dA_w, dA_b
+
+
+def soft_mask_max_regions():
+    return int(_lib.get().dasr_sean_soft_mask_max_regions())
 
 
 def mask_compress(mask):
@@ -315,8 +400,9 @@ def sean_fwd(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, 
     assert mask.shape == (B, K, H, W) and gb2.shape == (B, H, W, 2 * C) and D.shape == (B, 2, 9, K, C)
     out = torch.empty_like(t)
     rp, fp = _rf(region, flag)
-    _call("dasr_sean_fwd", _p(t), _p(mean), _p(var), _p(gb2), _p(mask), rp, fp, _p(D), _p(bias_g), _p(bias_b),
-          _p(alpha_g), _p(alpha_b), _p(residual, True), _p(out), int(relu), B, H, W, C, K, IN_EPS)
+    name = "dasr_sean_fwd_bf16" if _is_bf(t, gb2, residual) else "dasr_sean_fwd"
+    _call(name, _pa(t), _p(mean), _p(var), _pa(gb2), _p(mask), rp, fp, _p(D), _p(bias_g), _p(bias_b),
+          _p(alpha_g), _p(alpha_b), _pa(residual, True), _pa(out), int(relu), B, H, W, C, K, IN_EPS)
     return out
 
 
@@ -329,13 +415,14 @@ def sean_bwd(dout, out, t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b
     dt = torch.empty_like(t)
     dgb2 = torch.empty_like(gb2)
     dD = torch.empty_like(D)
-    dbg, dbb = empty((C,), t), empty((C,), t)
+    dbg, dbb = empty((C,), t), empty((C,), t)        # fp32 whatever the activation dtype
     dag, dab = empty((1,), t), empty((1,), t)
     dres = torch.empty_like(t) if want_dres else None
     rp, fp = _rf(region, flag)
-    _call("dasr_sean_bwd", _p(dout), _p(out), _p(t), _p(mean), _p(var), _p(gb2), _p(mask), rp, fp, _p(D), _p(bias_g),
-          _p(bias_b), _p(alpha_g), _p(alpha_b), _p(dt), _p(dgb2), _p(dD), _p(dbg), _p(dbb), _p(dag), _p(dab),
-          _p(dres, True), _p(ws), nbytes, int(relu), B, H, W, C, K, IN_EPS)
+    name = "dasr_sean_bwd_bf16" if _is_bf(dout, out, t, gb2) else "dasr_sean_bwd"
+    _call(name, _pa(dout), _pa(out), _pa(t), _p(mean), _p(var), _pa(gb2), _p(mask), rp, fp, _p(D), _p(bias_g),
+          _p(bias_b), _p(alpha_g), _p(alpha_b), _pa(dt), _pa(dgb2), _p(dD), _p(dbg), _p(dbb), _p(dag), _p(dab),
+          _pa(dres, True), _p(ws), nbytes, int(relu), B, H, W, C, K, IN_EPS)
     return dt, dgb2, dD, dbg, dbb, dag, dab, dres
 
 

@@ -35,8 +35,10 @@ class Tape:
     """Backward closures in forward order.  A closure recorded inside ``on_stream(s)`` runs its backward on ``s``
     too (the depth-map branch of every SEAN lives on a side stream, see graph.depthnet_forward)."""
 
-    def __init__(self, enabled=True):
+    def __init__(self, enabled=True, act_dtype=None):
+        import torch
         self.enabled = enabled
+        self.act_dtype = act_dtype if act_dtype is not None else torch.float32   # storage type of the trunk's activations
         self.nodes = []
         self._stream = None
         self.side_streams = []
@@ -87,6 +89,6 @@ def accum(var, g, owned=True):
         if owned:
             var.grad = g
         else:
-            var.grad = ops.copy_(ops.empty(g.shape, g), g)
+            var.grad = ops.copy_(ops.empty(g.shape, g, g.dtype), g)
     else:
         ops.accumulate_(var.grad, g)

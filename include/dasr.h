@@ -202,6 +202,12 @@ int dasr_sean_bwd(const float* dout, const float* out, const float* t, const flo
                   void* workspace, size_t workspace_bytes, int relu, int B, int H, int W, int C, int K, float eps,
                   void* stream);
 
+/* Largest K for which the soft-mask (general) kernels run forward and backward (their backward keeps two
+ * [2][9][K][64] tables in LDS).  With more regions (up to 16) only one-hot masks are supported: pass region bytes with
+ * onehot_flag NULL, i.e. read the flag of dasr_mask_compress yourself; otherwise dasr_sean_bwd returns
+ * DASR_E_UNSUPPORTED. */
+int dasr_sean_soft_mask_max_regions(void);
+
 /* ---- region-wise average pooling (depth matrix) ---------------------------------------------------
  * RegionWiseAvgPooling.forward (sftmd_arch.py:714-733): masks are resized to the feature size with
  * bilinear(align_corners=True) and re-binarised (>= 0.5) when sizes differ; per region
@@ -244,6 +250,61 @@ int dasr_loss_bwd(const float* sr, const float* hr, const unsigned char* region,
 int dasr_add(const float* a, const float* b, float* out, size_t n, void* stream);  /* torch.add, sftmd_arch.py:931 */
 int dasr_accumulate(float* dst, const float* src, size_t n, void* stream);         /* dst += src (gradient fan-in) */
 int dasr_copy(float* dst, const float* src, size_t n, void* stream);               /* device-to-device copy */
+
+/* ==== mixed precision: bf16 activations (BASELINE.json configs[2..3]) ================================================
+ * Replaces the same torch ops as the fp32 entry points when the reference is run under torch.autocast(bfloat16):
+ * nn.Conv2d / weight_norm convs (sftmd_arch.py:811-820,891-910), SEAN (normalization.py:37-42,52-92).  Activation tensors
+ * (unsigned short* = bf16 bits, NHWC) are bf16 in HBM; parameters, their gradients, instance-norm statistics, the dynamic
+ * kernels D and every accumulator are fp32.  Same conventions as above (asynchronous, no allocation, return codes).
+ * The bf16 path has no generic fallback kernels: unsupported geometries return DASR_E_UNSUPPORTED. */
+
+/* dasr_weight_pack_fwd with a bf16 packed kernel (normalisation in fp32, one rounding); dasr_weight_pack_bwd serves both. */
+int dasr_weight_pack_fwd_bf16(const float* v, const float* g, unsigned short* w, float* inv_norm, int O, int I, int KH, int KW,
+                              int transposed, int ldo, int o_off, void* stream);
+/* Convolution forward.  Three layer kinds, told apart by the geometry:
+ *   trunk   3x3 / stride 1 / pad 1, Cin % 32 == 0, Cout % 32 == 0 : x bf16, w packed bf16, y / residual bf16
+ *           (v_mfma_f32_32x32x16_bf16, fused bias / activation / PixelShuffle / residual as dasr_conv2d_fwd)
+ *   mask    3x3, Cin == 1 (SEAN.mlp_mask on the depth map)         : x f32,  w packed f32,  y bf16
+ *   output  9x9 / pad 4, Cout <= 3 (conv_output)                   : x bf16, w packed f32,  y f32 */
+int dasr_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, const unsigned short* residual, void* y, int B,
+                         int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int transposed,
+                         int act, int ps_r, void* stream);
+int dasr_conv2d_epilogue_bwd_bf16(const unsigned short* dy, const unsigned short* y, unsigned short* dconv, int B, int Ho,
+                                  int Wo, int Cout, int act, int ps_r, void* stream);
+/* trunk: dconv bf16, w packed bf16; output conv: dconv f32, w packed f32.  dx bf16. */
+int dasr_conv2d_dgrad_bf16(const void* dconv, const void* w, unsigned short* dx, int accumulate, int B, int H, int W, int Cin,
+                           int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int transposed, void* stream);
+size_t dasr_conv2d_wgrad_workspace_bf16(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                        int pad, int transposed);
+/* trunk: x bf16, dconv bf16; output conv: x bf16, dconv f32.  dw (plain HWIO) and dbias fp32. */
+int dasr_conv2d_wgrad_bf16(const unsigned short* x, const void* dconv, float* dw, float* dbias, void* workspace,
+                           size_t workspace_bytes, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                           int stride, int pad, int transposed, void* stream);
+/* mask layer: weight / bias gradient with the activation backward fused (x = depth map f32, dy / y bf16). */
+int dasr_conv2d_wgrad_act_bf16(const float* x, const unsigned short* dy, const unsigned short* y, float* dw, float* dbias,
+                               int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                               int transposed, int act, void* stream);
+/* dasr_instnorm_stats / dasr_sean_fwd / dasr_sean_bwd on bf16 activations (t, gb2, residual, out and their gradients);
+ * workspaces as for the fp32 entry points. */
+int dasr_instnorm_stats_bf16(const unsigned short* x, float* mean, float* var, void* workspace, size_t workspace_bytes, int B,
+                             int HW, int C, void* stream);
+int dasr_sean_fwd_bf16(const unsigned short* t, const float* mean, const float* var, const unsigned short* gb2,
+                       const float* mask, const unsigned char* region, const int* onehot_flag, const float* D,
+                       const float* bias_gamma, const float* bias_beta, const float* alpha_gamma, const float* alpha_beta,
+                       const unsigned short* residual, unsigned short* out, int relu, int B, int H, int W, int C, int K,
+                       float eps, void* stream);
+int dasr_sean_bwd_bf16(const unsigned short* dout, const unsigned short* out, const unsigned short* t, const float* mean,
+                       const float* var, const unsigned short* gb2, const float* mask, const unsigned char* region,
+                       const int* onehot_flag, const float* D, const float* bias_gamma, const float* bias_beta,
+                       const float* alpha_gamma, const float* alpha_beta, unsigned short* dt, unsigned short* dgb2, float* dD,
+                       float* dbias_gamma, float* dbias_beta, float* dalpha_gamma, float* dalpha_beta, unsigned short* dres,
+                       void* workspace, size_t workspace_bytes, int relu, int B, int H, int W, int C, int K, float eps,
+                       void* stream);
+/* elementwise helpers (n % 4 == 0) and the casts at the fp32 encoder <-> bf16 trunk boundary */
+int dasr_add_bf16(const unsigned short* a, const unsigned short* b, unsigned short* out, size_t n, void* stream);
+int dasr_accumulate_bf16(unsigned short* dst, const unsigned short* src, size_t n, void* stream);
+int dasr_cast_f32_to_bf16(const float* src, unsigned short* dst, size_t n, void* stream);
+int dasr_cast_bf16_to_f32(const unsigned short* src, float* dst, int accumulate, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -146,3 +146,60 @@ static inline f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, i
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
+
+// ---- bf16 MFMA (v_mfma_f32_32x32x16_bf16): A lane (r = l&31, h = l>>5) holds A[row r][k = 8h + j], B lane holds
+// B[k = 8h + j][col r], j = 0..7; C/D as the f32 form (cdna_hip_programming.md section 3).  Products of two bf16 values are
+// exact in fp32; the accumulation is emulated as an fp32 fma chain in k order.
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline float hipemu_bf2f(__bf16 b) {
+    unsigned short h;
+    memcpy(&h, &b, 2);
+    unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, f32x16 c, int, int, int) {
+    char* buf = (char*)hipemu::wave_buf();
+    int l = hipemu::lane_id();
+    memcpy(buf + 64 * l, &a, 16);
+    memcpy(buf + 64 * l + 16, &b, 16);
+    hipemu::wave_barrier();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            __bf16 av, bv;
+            memcpy(&av, buf + 64 * (row + 32 * (k >> 3)) + 2 * (k & 7), 2);
+            memcpy(&bv, buf + 64 * (col + 32 * (k >> 3)) + 16 + 2 * (k & 7), 2);
+            acc = fmaf(hipemu_bf2f(av), hipemu_bf2f(bv), acc);
+        }
+        c[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
+
+// ---- ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per group of 16 consecutive lanes, lane 4q+p supplies the address
+// of row q, columns 4p..4p+3 of a 4 x 16 block of 16-bit elements; lane i of the group receives column i, row q in its
+// element q.
+typedef short hipemu_s16x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_s16x4 hipemu_ds_read_tr16_b64(const void* addr) {
+    char* buf = (char*)hipemu::wave_buf();
+    int l = hipemu::lane_id();
+    memcpy(buf + 64 * l, &addr, sizeof(void*));
+    hipemu::wave_barrier();
+    int g = l >> 4, i = l & 15;
+    hipemu_s16x4 out;
+    for (int q = 0; q < 4; ++q) {
+        const char* src;
+        memcpy(&src, buf + 64 * (16 * g + 4 * q + (i >> 2)), sizeof(void*));
+        short v;
+        memcpy(&v, src + 2 * (i & 3), 2);
+        out[q] = v;
+    }
+    hipemu::wave_barrier();
+    return out;
+}

@@ -96,3 +96,17 @@ def test_replica_protocol(emu):
 
 def test_region_shortcut_invalidation(emu):
     print(pc.check_region_shortcut_invalidation("cpu"))
+
+
+def test_bf16_conv_variants(emu):
+    print(pc.check_bf16_conv_variants("cpu"))
+
+
+@pytest.mark.parametrize("name", ["x8_nb4", "x4_nb4"])
+def test_bf16_depthnet(emu, name):
+    case = [c for c in DEPTHNET_CASES if c["name"] == name][0]
+    print(name, pc.check_bf16_depthnet_case(case, "cpu"))
+
+
+def test_bf16_ops_vs_fp32_kernels(emu):
+    print(pc.check_bf16_ops_vs_fp32_kernels("cpu"))

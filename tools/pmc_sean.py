@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM bytes per launch of k_sean_fwd_onehot from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; --output-format
 csv) over `tools/bench_ops.py --batch B --only sean` -> profiles/sean_fwd_pmc.json (read by bench.py for roofline.traffic).
-Usage: python tools/pmc_sean.py <fetch dir> <write dir> [B]"""
+Usage: python tools/pmc_sean.py <fetch dir> <write dir> [B]   (B != 16 writes profiles/sean_fwd_pmc_b<B>.json)"""
 import collections
 import csv
 import glob
@@ -37,6 +37,6 @@ out = {
     "hbm_bytes_per_launch": (hbm["nores"] + hbm["res"]) / 2,
     "algorithmic_bytes_per_launch": (px * (16 * C + 4 * K) + px * (20 * C + 4 * K)) / 2,
 }
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "sean_fwd_pmc.json")
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "sean_fwd_pmc.json" if B == 16 else "sean_fwd_pmc_b%d.json" % B)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
