@@ -28,6 +28,21 @@ from dasr_amd import harness, networks, ops, prep, synth
 
 LR_H, LR_W, SCALE, K_REGIONS = 128, 160, 8, 10
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (same guide; AMD's 5 PF headline includes 2:1 sparsity)
+
+# BASELINE.json configs.  c2 = configs[1] is the headline (the default, what the driver runs); c3 = configs[2] is the
+# bf16 parity / roofline case, selected explicitly with --config c3 and never the default.
+CONFIGS = {
+    "c2": dict(scale=8, lr_hw=(128, 160), batch=16, dtype="f32",
+               workload="Kvasir x8 synthetic, batch=%d per GPU, fp32, DepthNet nb=16 nf=64 L=256 K=10 (BASELINE.json "
+                        "configs[1]); step = fwd + L1 + dynamic loss + bwd + Adam"),
+    "c3": dict(scale=4, lr_hw=(256, 320), batch=32, dtype="bf16",
+               workload="Kvasir x4 synthetic, batch=%d per GPU, bf16 activations + bf16-MFMA trunk convs (fp32 master "
+                        "weights / statistics / accumulators), DepthNet nb=16 nf=64 L=256 K=10, LR 256x320 (BASELINE.json "
+                        "configs[2]); step = fwd + L1 + dynamic loss + bwd + Adam"),
+}
+# algorithmic FLOPs of the trunk per frame, forward + backward
+TRUNK_GFLOP_PER_FRAME = {"c2": 848.0, "c3": 2685.0}
 
 
 def sean_algorithmic_bytes(B, H, W, C, K, residual):
@@ -88,6 +103,72 @@ class SeanTimer:
                 ms = sum(p[0].elapsed_time(p[1]) for p in sel) / len(sel)
                 out[res] = (ms, len(sel), sean_algorithmic_bytes(*sel[0][3]), sean_kernel_bytes(*sel[0][3]))
         return out
+
+
+class ConvTimer:
+    """HIP events around the forward launches of the trunk's dominant convolution (the gamma_o | beta_o 128 -> 128
+    convs: 55 % of the trunk's forward FLOPs), on their launch stream."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+        self._orig = ops.conv2d_fwd
+
+    def install(self):
+        orig = self._orig
+
+        def timed(x, w, *a, **k):
+            hot = self.enabled and x.dim() == 4 and x.shape[3] == 128 and w.shape[4] == 128 and w.shape[1] == 3
+            if not hot:
+                return orig(x, w, *a, **k)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(x, w, *a, **k)
+            e1.record()
+            B, H, W, _ = x.shape
+            self.pairs.append((e0, e1, 2.0 * 9 * 128 * 128 * B * H * W))
+            return out
+
+        ops.conv2d_fwd = timed
+        from dasr_amd import graph as g
+        g.ops.conv2d_fwd = timed
+
+
+def mfma_roofline(net, args, B, elapsed, timer_conv):
+    """c3 (bf16): the step is bound by the bf16 matrix cores.  `achieved` = algorithmic FLOPs of one launch of the
+    dominant kernel (k_conv3x3_bf16 on the 128 -> 128 gamma_o|beta_o convolution, 2*9*128*128 FLOP per pixel) / its
+    average launch duration, measured with HIP events in one extra un-overlapped forward after the timed region; the
+    whole step's trunk FLOPs (2685 GFLOP per frame fwd+bwd) over the step time are reported next to it."""
+    from dasr_amd import graph as _graph
+    lq, dm, mk = net._bench_inputs
+    side = _graph.SIDE_STREAM
+    _graph.SIDE_STREAM = False
+    try:
+        with torch.no_grad():
+            timer_conv.pairs = []
+            timer_conv.enabled = True
+            net(lq, dm, mk)
+            torch.cuda.synchronize()
+            timer_conv.enabled = False
+    finally:
+        _graph.SIDE_STREAM = side
+    if not timer_conv.pairs:
+        return None
+    ms = [a.elapsed_time(b) for a, b, _ in timer_conv.pairs]
+    flops = timer_conv.pairs[0][2]
+    avg_ms = sum(ms) / len(ms)
+    ach = flops / (avg_ms * 1e-3) / 1e12
+    step_tf = TRUNK_GFLOP_PER_FRAME["c3"] * 1e9 * B * args.steps / elapsed / 1e12
+    return {"bound": "mfma", "kernel": "k_conv3x3_bf16<NT=2> (dasr_conv2d_fwd_bf16, 128->128 gamma_o|beta_o conv, forward)",
+            "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFS, 4),
+            "traffic": None, "launches_timed": len(ms), "avg_launch_us": round(avg_ms * 1e3, 2),
+            "algorithmic_flops_per_launch": flops,
+            "measured": "HIP events on the launch stream, one un-overlapped forward pass after the timed region",
+            "whole_step": {"trunk_gflop_per_frame_fwd_bwd": TRUNK_GFLOP_PER_FRAME["c3"], "achieved_tflops": round(step_tf, 1),
+                           "frac_of_bf16_mfma_peak": round(step_tf / MFMA_BF16_PEAK_TFS, 4),
+                           "note": "the 9x9 output conv and the fp32 encoder run on the fp32 matrix cores; SEAN, "
+                                   "statistics and epilogue-backward kernels are HBM-bound"}}
 
 
 def host_cores():
@@ -163,7 +244,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU (configs[1]: 16)")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json config (default c2 = configs[1])")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: c2 16, c3 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the forward-only batch-32 roofline pass")
     args = ap.parse_args()
@@ -184,12 +266,17 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
 
-    opt = {"network_G": dict(networks.X8_NETWORK_G), "datasets": {"train": {"depthMaskNum": K_REGIONS}}}
+    cfg = CONFIGS[args.config]
+    global LR_H, LR_W, SCALE
+    (LR_H, LR_W), SCALE = cfg["lr_hw"], cfg["scale"]
+    opt = {"network_G": dict(networks.X8_NETWORK_G, upscale=SCALE), "datasets": {"train": {"depthMaskNum": K_REGIONS}}}
     net = networks.define_G(opt)
     synth.closed_form_fill_(net.state_dict().items())
     net = net.to(dev)
+    if cfg["dtype"] == "bf16":
+        net.set_compute_dtype(torch.bfloat16)          # explicit: fp32 is what every other path of this repo runs
     trainer = harness.Trainer(net, K_REGIONS, group=group)
-    B = args.batch
+    B = args.batch or cfg["batch"]
     lq, gt, dm, mk_host = synth.seeded_batch(rank * B, B, LR_H, LR_W, SCALE, K_REGIONS)
     lq, gt, dm = lq.to(dev), gt.to(dev), dm.to(dev)
     # the depth masks are derived from the depth map ON THE DEVICE (prep.depth_to_masks = getDepthMask, pinned to the
@@ -198,9 +285,13 @@ def main():
     mk = prep.depth_to_masks(dm, K_REGIONS)
     assert torch.equal(mk.cpu(), mk_host), "device-side getDepthMask differs from the host rule"
     del mk_host
+    object.__setattr__(net, "_bench_inputs", (lq, dm, mk))
 
     timer = SeanTimer()
     timer.install()
+    timer_conv = ConvTimer()
+    if args.config == "c3":
+        timer_conv.install()
 
     def barrier():
         if world > 1:
@@ -281,7 +372,7 @@ def main():
     # (13 launches without / 13 with the residual read); both byte counts are reported: SURVEY §8d's (K mask floats as
     # delivered) and the kernel's true minimum (one region byte).
     roof32 = None
-    if rank == 0 and not args.no_b32:
+    if rank == 0 and not args.no_b32 and args.config == "c2":
         note("forward-only pass at batch 32 for roofline_b32")
         del trainer
         net.zero_grad(set_to_none=True)
@@ -330,21 +421,24 @@ def main():
                     pass
         del lq32, dm32, mk32
 
+    if args.config == "c3":
+        roof = mfma_roofline(net, args, B, elapsed, timer_conv)
+
     if rank == 0:
         out = {
-            "metric": "LR frames/sec fwd+bwd at x8 (128x160 LR)", "value": round(world * B * args.steps / elapsed, 3),
+            "metric": "LR frames/sec fwd+bwd at x%d (%dx%d LR)" % (SCALE, LR_H, LR_W),
+            "value": round(world * B * args.steps / elapsed, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Kvasir x8 synthetic, batch=%d per GPU, fp32, DepthNet nb=16 nf=64 L=256 K=10 "
-                                   "(BASELINE.json configs[1]); step = fwd + L1 + dynamic loss + bwd + Adam" % B,
+            "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": cfg["workload"] % B,
                        "global_batch": world * B, "lr_hw": [LR_H, LR_W], "scale": SCALE,
                        "parallelism": "dp%d" % world},
             "loss": round(loss, 6),
             "roofline": roof,
             "roofline_b32": roof32,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             note("GPU part done (%.1f ms/step); timing the CPU oracle baseline" % (1e3 * elapsed / args.steps))
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

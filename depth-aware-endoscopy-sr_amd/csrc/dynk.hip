@@ -117,58 +117,81 @@ __global__ void __launch_bounds__(256) k_dynk_dW_mfma(const float* __restrict__ 
         (st2 >= 9 ? dWb : dWg)[((size_t)c2 * L + n) * 9 + (st2 % 9)] = acc[r];
     }
 }
-// dstp[b,k,l] = sum_{s,tap,c} dD[b,s,tap,k,c] * W_s[c,l,tap]; blockIdx.y = (s,tap) slice, partial sums are
-// added with float atomics into the zeroed dstp (18 adds per element)
-__global__ void k_dynk_dstp(const float* __restrict__ dD, const float* __restrict__ Wg, const float* __restrict__ Wb,
-                            float* __restrict__ dstp, int K, int L, int C, size_t n) {
-    const int st = blockIdx.y, s = st / 9, tap = st % 9;
-    const float* Wp = s ? Wb : Wg;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int l = (int)(i % L), k = (int)((i / L) % K);
-        size_t b = i / ((size_t)L * K);
-        const float* dp = dD + ((b * 18 + st) * K + k) * C;
-        float acc = 0.f;
-        for (int c0 = 0; c0 < C; c0 += 8) {            // eight (dD, W) pairs in flight; same summation order
-            float dv[8], wv[8];
+// dstp[b,k,l] = sum_{s,tap,c} dD[b,s,tap,k,c] * W_s[c,l,tap]      M = (b,k), N = l, K = (s,tap,c) = 18*C
+// One workgroup = one 32x32 output tile, six waves each contracting three (s,tap) slices (3*C of the 18*C terms) on
+// v_mfma_f32_32x32x2_f32; the six partial tiles meet in LDS and are summed in a fixed order (no atomics, no memset:
+// the one-thread-per-output version with an 18-way float-atomic fan-in took 58 us alone and 527 us inside the step).
+#define DSTP_WAVES 6
+__global__ void __launch_bounds__(64 * DSTP_WAVES) k_dynk_dstp_mfma(const float* __restrict__ dD, const float* __restrict__ Wg,
+                                                                    const float* __restrict__ Wb, float* __restrict__ dstp,
+                                                                    int B, int K, int L, int C) {
+    __shared__ float part[DSTP_WAVES][32][33];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int M = B * K, N = L;
+    const int tiles_n = (N + 31) / 32;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    const int m = m0 + li, n = n0 + li;
+    const bool mv = m < M, nv = n < N;
+    const int b = mv ? m / K : 0, k = mv ? m % K : 0;
+    f32x16 acc;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = c0 + u < C ? c0 + u : C - 1;
-                dv[u] = dp[c];
-                wv[u] = Wp[((size_t)c * L + l) * 9 + tap];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int q = 0; q < 18 / DSTP_WAVES; ++q) {
+        const int st = wv * (18 / DSTP_WAVES) + q, tap = st % 9;
+        const float* ap = dD + (((size_t)b * 18 + st) * K + k) * C;                  // + c
+        const float* bp = (st >= 9 ? Wb : Wg) + (size_t)(nv ? n : 0) * 9 + tap;     // + c * L * 9
+        for (int c0 = lh; c0 < C; c0 += 32) {      // sixteen K steps per trip, all 32 loads issued before the first MFMA
+            float av[16], bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = c0 + 2 * u;
+                av[u] = (mv && c < C) ? ap[c] : 0.f;
+                bv[u] = (nv && c < C) ? bp[(size_t)c * L * 9] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (c0 + u < C) acc = fmaf(dv[u], wv[u], acc);
+            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
         }
-        atomicAdd(&dstp[i], acc);
     }
-}
-// dA_w[k,j] = sum_{b,l} dstp[b,k,l]*st[b,j,l]; dA_b[k] = sum_{b,l} dstp[b,k,l]; one workgroup per output
-__global__ void __launch_bounds__(256) k_dynk_dA(const float* __restrict__ dstp, const float* __restrict__ st,
-                                                 float* __restrict__ dA_w, float* __restrict__ dA_b, int B, int K,
-                                                 int L) {
-    __shared__ float red[4];
-    const int e = blockIdx.x;
-    const bool is_bias = e >= K * K;
-    const int k = is_bias ? e - K * K : e / K, j = is_bias ? 0 : e % K;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < B * L; i += 256) {
-        int b = i / L, l = i % L;
-        float d = dstp[((size_t)b * K + k) * L + l];
-        acc += is_bias ? d : d * st[((size_t)b * K + j) * L + l];
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wv][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float r = red[0] + red[1] + red[2] + red[3];
-        if (is_bias) dA_b[k] = r; else dA_w[e] = r;
+    for (int e = threadIdx.x; e < 32 * 32; e += 64 * DSTP_WAVES) {
+        const int row = e >> 5, col = e & 31;
+        float sum = part[0][row][col];
+#pragma unroll
+        for (int w = 1; w < DSTP_WAVES; ++w) sum += part[w][row][col];
+        if (m0 + row < M && n0 + col < N) dstp[(size_t)(m0 + row) * L + n0 + col] = sum;
     }
 }
-// dst[b,j,l] += sum_k A_w[k,j] * dstp[b,k,l]
-__global__ void k_dynk_dst(const float* __restrict__ dstp, const float* __restrict__ A_w, float* __restrict__ dst,
-                           int K, int L, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+// One launch for the two small tails: blocks [0, K*K+K): dA_w[k,j] = sum_{b,l} dstp[b,k,l]*st[b,j,l] and
+// dA_b[k] = sum_{b,l} dstp[b,k,l] (one workgroup per output); the other blocks: dst[b,j,l] += sum_k A_w[k,j]*dstp[b,k,l]
+__global__ void __launch_bounds__(256) k_dynk_dA_dst(const float* __restrict__ dstp, const float* __restrict__ st,
+                                                     const float* __restrict__ A_w, float* __restrict__ dA_w,
+                                                     float* __restrict__ dA_b, float* __restrict__ dst, int B, int K,
+                                                     int L, size_t n) {
+    __shared__ float red[4];
+    const int nA = K * K + K;
+    if ((int)blockIdx.x < nA) {
+        const int e = blockIdx.x;
+        const bool is_bias = e >= K * K;
+        const int k = is_bias ? e - K * K : e / K, j = is_bias ? 0 : e % K;
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < B * L; i += 256) {
+            int b = i / L, l = i % L;
+            float d = dstp[((size_t)b * K + k) * L + l];
+            acc += is_bias ? d : d * st[((size_t)b * K + j) * L + l];
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float r = red[0] + red[1] + red[2] + red[3];
+            if (is_bias) dA_b[k] = r; else dA_w[e] = r;
+        }
+        return;
+    }
+    const size_t nblk = gridDim.x - nA;
+    for (size_t i = (size_t)(blockIdx.x - nA) * 256 + threadIdx.x; i < n; i += nblk * 256) {
         int l = (int)(i % L), j = (int)((i / L) % K);
         size_t b = i / ((size_t)L * K);
         float acc = 0.f;
@@ -187,10 +210,14 @@ extern "C" int dasr_dynk_bwd(const float* dD, const float* st, const float* stp,
     (void)nW;
     {
         int tiles = ((18 * C + 31) / 32) * ((L + 31) / 32);
-        DASR_LAUNCH(k_dynk_dW_mfma, dim3((tiles + 3) / 4), dim3(256), 0, stream, dD, stp, dWg, dWb, B, K, L, C, dstp, nS);
+        DASR_LAUNCH(k_dynk_dW_mfma, dim3((tiles + 3) / 4), dim3(256), 0, stream, dD, stp, dWg, dWb, B, K, L, C,
+                    (float*)nullptr, (size_t)0);
     }
-    DASR_LAUNCH(k_dynk_dstp, dim3(dasr_ew_grid(nS), 18), dim3(256), 0, stream, dD, Wg, Wb, dstp, K, L, C, nS);
-    DASR_LAUNCH(k_dynk_dA, dim3(K * K + K), dim3(256), 0, stream, dstp, st, dA_w, dA_b, B, K, L);
-    DASR_LAUNCH(k_dynk_dst, dim3(dasr_ew_grid(nS)), dim3(256), 0, stream, dstp, A_w, dst, K, L, nS);
+    {
+        int tiles = ((B * K + 31) / 32) * ((L + 31) / 32);
+        DASR_LAUNCH(k_dynk_dstp_mfma, dim3(tiles), dim3(64 * DSTP_WAVES), 0, stream, dD, Wg, Wb, dstp, B, K, L, C);
+    }
+    DASR_LAUNCH(k_dynk_dA_dst, dim3(K * K + K + dasr_ew_grid(nS)), dim3(256), 0, stream, (const float*)dstp, st, A_w, dA_w,
+                dA_b, dst, B, K, L, nS);
     DASR_RETURN_LAUNCH_STATUS();
 }

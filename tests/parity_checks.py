@@ -1101,6 +1101,8 @@ def check_bf16_conv_variants(device, seed=0):
         (64, 32, 2, 1, False, 1, 7, 40), (128, 128, 0, 1, False, 1, 8, 32), (64, 256, 2, 2, False, 1, 6, 32),
         (32, 128, 2, 2, False, 1, 10, 35), (64, 288, 2, 3, False, 1, 5, 32), (64, 64, 1, 1, True, 1, 8, 30),
     ]
+    if device != "cpu":        # BASELINE.json configs[2] frame size: many tile rounds, both N slices, 8 XCD-ordered waves of blocks
+        cases += [(64, 64, 0, 1, False, 2, 256, 320), (128, 128, 0, 1, False, 1, 256, 320), (32, 128, 2, 2, False, 1, 512, 640)]
     worst = {}
     for (cin, cout, act, ps, res, B, H, W) in cases:
         x = _bf(rn(B, cin, H, W))
@@ -1140,8 +1142,8 @@ def check_bf16_conv_variants(device, seed=0):
         e3 = rel_max(dw.permute(3, 2, 0, 1), gw)
         e4 = rel_max(db, gb)
         assert e3 <= 1e-5 and e4 <= 1e-5, ("wgrad", cin, cout, e3, e4)
-        worst[(cin, cout, ps)] = (e, e1, e2, e3, e4)
-    return {"%d->%d ps%d" % k: tuple(round(v, 7) for v in vs) for k, vs in worst.items()}
+        worst[(cin, cout, ps, H)] = (e, e1, e2, e3, e4)
+    return {"%d->%d ps%d H%d" % k: tuple(round(v, 7) for v in vs) for k, vs in worst.items()}
 
 
 def digest_cosine(named_grads, golden, prefix, skip=()):
@@ -1324,3 +1326,61 @@ def check_bf16_ops_vs_fp32_kernels(device, seed=1):
     cp = torch.empty_like(h(a))
     assert torch.equal(ops.copy_(cp, h(a)), h(a))
     return out
+
+
+def check_bf16_c3_full_frame(device="cuda"):
+    """BASELINE.json configs[2] at its full frame size (x4 net, nb=16, L=256, DGBs 0..13, one 256x320 LR frame ->
+    1024x1280) on the bf16 path, against the fp32 CPU oracle (forward: north_star's reduced-precision bar,
+    |PSNR(out_bf16, GT) - PSNR(out_oracle, GT)| <= 0.02 dB) and against this repo's fp32 HIP path on the same weights
+    (harness-loss gradients: relative L2 and cosine, gated at ~3x / well below the values measured on the MI355X)."""
+    case = dict(name="c3", scale=4, which=list(range(14)), L=256, nb=16, B=1, H=256, W=320)
+    net, cfg = build_net(case, device)
+    lq, gt, dm, mk = synth.closed_form_batch(0, 1, case["H"], case["W"], 4)
+    sd = _oracle_sd(net)
+    with torch.no_grad():
+        ref = O.depthnet_forward(sd, cfg, lq, dm, mk)
+    lqd, gtd, dmd, mkd = [t.to(device) for t in (lq, gt, dm, mk)]
+    res = {}
+    for dt in (torch.float32, BF16):
+        net.set_compute_dtype(dt)
+        net.zero_grad(set_to_none=True)
+        sr = net(lqd, dmd, mkd)
+        w = torch.ones(10, device=device, requires_grad=True)
+        total, l_pix, l_dyn, _ = O.total_loss(sr, gtd, mkd, w)
+        total.backward()
+        res[dt] = (sr.detach().cpu(), float(l_pix), float(l_dyn),
+                   {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    sr32, sr16 = res[torch.float32][0], res[BF16][0]
+    assert tuple(sr16.shape) == (1, 3, 1024, 1280)
+    dpsnr32 = abs(O.psnr_255(sr32, gt) - O.psnr_255(ref, gt))
+    dpsnr16 = abs(O.psnr_255(sr16, gt) - O.psnr_255(ref, gt))
+    psnr16 = O.psnr_255(sr16, ref)
+    num = den = dot = nb = 0.0
+    for k, a in res[torch.float32][3].items():
+        if any(z in k for z in ZERO_GRAD_KEYS):
+            continue
+        b = res[BF16][3][k]
+        assert bool(torch.isfinite(b).all()), k
+        a, b = a.double(), b.double()
+        num += (a - b).pow(2).sum().item()
+        den += a.pow(2).sum().item()
+        dot += (a * b).sum().item()
+        nb += b.pow(2).sum().item()
+    rel, cos = math.sqrt(num / den), dot / math.sqrt(den * nb)
+    out = dict(dpsnr_fp32=dpsnr32, dpsnr_bf16=dpsnr16, psnr_bf16_vs_oracle=psnr16,
+               max_err_bf16=(sr16 - ref).abs().max().item(), loss_grad_rel_l2_bf16_vs_fp32=rel, loss_grad_cosine=cos,
+               l_pix=(res[torch.float32][1], res[BF16][1]), l_dyn=(res[torch.float32][2], res[BF16][2]))
+    print("bf16 c3 full frame:", out)
+    assert dpsnr32 <= 1e-3, dpsnr32                 # the fp32 path: north_star's fp32 bar
+    assert dpsnr16 <= 0.02, dpsnr16                 # the bf16 path: north_star's reduced-precision bar
+    # 13 DGBs deep, every stored activation carries 8 significant bits and each block's two instance norms re-amplify
+    # the noise of the one before: measured 32.3 dB against the fp32 oracle's image on the MI355X (45 .. 48 dB for the
+    # two-block golden cases); the floor only catches a broken kernel
+    assert psnr16 >= 28.0, psnr16
+    assert rel <= BF16_C3_GRAD_GATE[0] and cos >= BF16_C3_GRAD_GATE[1], (rel, cos)
+    return out
+
+
+# harness-loss gradients of the bf16 path vs this repo's fp32 path at c3's frame size: (max rel-L2, min cosine); set from
+# the values measured on the MI355X (profiles/r02_gpu_tests.log)
+BF16_C3_GRAD_GATE = (0.6, 0.9)

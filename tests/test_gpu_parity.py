@@ -183,3 +183,25 @@ def test_ddp_single_rank():
 @pytest.mark.gpu
 def test_region_shortcut_invalidation():
     print(pc.check_region_shortcut_invalidation("cuda"))
+
+
+@pytest.mark.gpu
+def test_bf16_conv_variants():
+    print(pc.check_bf16_conv_variants("cuda"))
+
+
+@pytest.mark.gpu
+def test_bf16_ops_vs_fp32_kernels():
+    print(pc.check_bf16_ops_vs_fp32_kernels("cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["x8_nb4", "x4_nb4"])
+def test_bf16_depthnet(name):
+    case = [c for c in DEPTHNET_CASES if c["name"] == name][0]
+    print(name, pc.check_bf16_depthnet_case(case, "cuda"))
+
+
+@pytest.mark.gpu
+def test_bf16_c3_full_frame():
+    print(pc.check_bf16_c3_full_frame("cuda"))

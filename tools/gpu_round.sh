@@ -1,12 +1,14 @@
+# one GPU-box visit: GPU tests (log kept), fp32 bench, bf16 c3 bench, rocprof of both; outputs under gpurun_out/$1
 export TMPDIR=/tmp
-O=gpurun_out/r2a; mkdir -p $O
-timeout -k 10 1000 python -m pytest tests -m gpu -q -rA -s > $O/gpu_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -5 $O/gpu_tests.log
+O=gpurun_out/${1:-r2}; mkdir -p $O
+timeout -k 10 1000 python -m pytest tests -m gpu -q -rA -s > $O/gpu_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -8 $O/gpu_tests.log
 if [ $rc -ge 124 ]; then exit $rc; fi
-timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; rc=$?; echo "bench rc=$rc"; cat $O/bench.json
+timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; rc=$?; echo "bench rc=$rc"; cat $O/bench.json | cut -c1-600
+if [ $rc -ge 124 ]; then exit $rc; fi
+timeout -k 10 400 python bench.py --config c3 --steps 3 --warmup 1 > $O/bench_c3.json 2> $O/bench_c3.err; rc=$?; echo "bench c3 rc=$rc"; cat $O/bench_c3.json; tail -3 $O/bench_c3.err
 if [ $rc -ge 124 ]; then exit $rc; fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof -o bench --output-format csv -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_prof.json 2> $O/bench_prof.err; echo "prof rc=$?"
-python tools/sean_split.py $O/prof 1 3 $O/sean_split.json > /dev/null; python tools/kstats.py $O/prof 40 > $O/kstats.txt
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- python3 tools/bench_ops.py --batch 32 --only sean --iters 3 > $O/pmc_fetch.log 2>&1 && \
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- python3 tools/bench_ops.py --batch 32 --only sean --iters 3 > $O/pmc_write.log 2>&1 && \
-python tools/pmc_sean.py $O/pmc_fetch $O/pmc_write 32 > $O/pmc32.json; cp profiles/sean_fwd_pmc_b32.json $O/ 2>/dev/null
+python tools/sean_split.py $O/prof 1 3 $O/sean_split.json > /dev/null; python tools/kstats.py $O/prof 45 > $O/kstats.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_c3 -o bench --output-format csv -- python3 bench.py --config c3 --steps 2 --warmup 1 > $O/bench_c3_prof.json 2> $O/bench_c3_prof.err; echo "prof c3 rc=$?"
+python tools/kstats.py $O/prof_c3 45 > $O/kstats_c3.txt
 ls $O
