@@ -104,3 +104,33 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const bf16_t* p) {
     __builtin_memcpy(&v, &r, 8);
     return v;
 }
+
+// ---- 16-byte loads through a buffer descriptor -------------------------------------------------------------------------
+// buffer_load_dwordx4 with a 128-bit resource (base, num_records): the address is base + a 32-bit byte offset and the
+// hardware range-checks it - an offset at or beyond num_records returns zeros.  The staging loops of the bf16 convolutions
+// use that as the convolution's zero padding: per-piece offsets are computed once per tile, pieces outside the image get
+// DASR_OOB, and the per-chunk loop is "add the chunk offset, load" with no index arithmetic, compares or branches
+// (the predicated global loads it replaces cost ~25 VALU instructions and an exec-mask branch per piece per chunk,
+// more than the MFMA work of a 32-channel bf16 chunk).  The descriptor must be built from wave-uniform values.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#define DASR_OOB 0x80000000u       // + any chunk offset stays out of range: tensors addressed this way are < 2 GiB
+#ifdef DASR_HIPEMU
+struct BufRsrc {
+    const char* base;
+    size_t bytes;
+};
+static inline BufRsrc dasr_make_rsrc(const void* p, size_t bytes) { return BufRsrc{(const char*)p, bytes}; }
+static inline u32x4_t dasr_buffer_load16(const BufRsrc& r, unsigned off) {
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if ((size_t)off + 16 <= r.bytes) memcpy(&v, r.base + off, 16);
+    return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc dasr_make_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4_t dasr_buffer_load16(BufRsrc r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+}
+#endif

@@ -27,12 +27,7 @@
 #include "conv_kernels.h"
 
 #define CB_TW 32
-#define CB_CK 32
-#define CB_CKP 40
 #define CB_HALO_W (CB_TW + 2)
-#define CB_MTW 2
-#define CB_TH (4 * CB_MTW)
-#define CB_HALO_H (CB_TH + 2)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -46,12 +41,21 @@ struct ConvBf16Args {
     int act, ps_r, accumulate;
 };
 
-template <int NT, int WMODE>
-__global__ void __launch_bounds__(256, 2) k_conv3x3_bf16(ConvBf16Args a) {
+// NW = waves per workgroup: 4 (8-row tiles, two workgroups per CU) or 8 (16-row tiles, one 512-thread workgroup per CU:
+// the kernel slice - 60 % of the staged bytes - is written to LDS once for twice the pixels).  NT = 32-channel N tiles
+// per workgroup: with NT = 4 (a 128-channel output in one workgroup) a wave issues 6 operand reads per 8 MFMAs instead
+// of 4 per 4, and the input tile is fetched once instead of once per N slice.  LDS is the contended resource of this
+// kernel (operand reads + staging writes were 82 % of the CU's LDS cycles at NW = 4 / NT = 2: 868 TF on 128 -> 128).
+// CB_MTW = tile rows per wave: 2, or 4 (32-row tiles with NW = 8: 6 operand reads per 8 MFMAs, the kernel slice staged
+// once per 1024 pixels - LDS cycles per MFMA drop from 82 % to 56 % of the pipe time; 128 accumulator registers).
+template <int NT, int WMODE, int NW, int CB_MTW, int CK>
+__global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
     DASR_DYN_SMEM(smem);
+    constexpr int NTHR = 64 * NW, CB_TH = CB_MTW * NW, CB_HALO_H = CB_TH + 2;
+    constexpr int CKP = CK + 8, PPX = CK / 8;        // LDS stride (odd multiple of 16 B), 16-byte pieces per pixel / channel row
     constexpr int NTILE = 32 * NT;
     bf16_t* sIn = (bf16_t*)smem;                                  // [HALO_H*HALO_W][CKP]
-    bf16_t* sW = sIn + CB_HALO_H * CB_HALO_W * CB_CKP;            // [9][NTILE][CKP]
+    bf16_t* sW = sIn + CB_HALO_H * CB_HALO_W * CKP;            // [9][NTILE][CKP]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     // XCD-aware block order: the N-slices of one pixel tile get workgroup ids 8 apart (same XCD, back to back)
@@ -72,70 +76,71 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_bf16(ConvBf16Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    constexpr int NINP = CB_HALO_H * CB_HALO_W * 4;               // 16-byte pieces of the halo tile (4 per pixel)
-    constexpr int NWTP = 9 * NTILE * 4;
-    constexpr int NIN = (NINP + 255) / 256, NWT = (NWTP + 255) / 256;
+    constexpr int NINP = CB_HALO_H * CB_HALO_W * PPX;             // 16-byte pieces of the halo tile
+    constexpr int NWTP = 9 * NTILE * PPX;
+    constexpr int NIN = (NINP + NTHR - 1) / NTHR, NWT = (NWTP + NTHR - 1) / NTHR;
     u32x4 pin[NIN], pwt[NWT];
+    // Piece addressing is computed ONCE per workgroup: a byte offset per piece from the sample's / the kernel slice's base
+    // (DASR_OOB for halo pixels outside the image: the buffer load returns the zero padding), so that the per-chunk loop
+    // below is one add and one buffer load per piece.
     const bf16_t* wsrc = WMODE == 0 ? a.w + (size_t)9 * a.Cin * a.Cout : a.w;
+    const BufRsrc rx = dasr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.Cin, (size_t)a.H * a.W * a.Cin * sizeof(bf16_t));
+    const BufRsrc rw = dasr_make_rsrc(wsrc, (size_t)9 * a.Cin * a.Cout * sizeof(bf16_t));
+    unsigned offx[NIN], offw[NWT];
+#pragma unroll
+    for (int u = 0; u < NIN; ++u) {
+        const int idx = tid + NTHR * u;
+        const int pix = idx / PPX, q4 = idx % PPX;
+        const int gy = y0 + pix / CB_HALO_W - 1, gx = x0 + pix % CB_HALO_W - 1;
+        const bool ok = idx < NINP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        offx[u] = ok ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * q4) * (int)sizeof(bf16_t)) : DASR_OOB;
+    }
+    // kernel slice as [tap][n][k], k contiguous in both modes:
+    //   forward: second half of the packed kernel, [tap][co][ci];  dgrad: first half (HWIO = [tap][n = ci_f][k = co_f]),
+    //   taps flipped
+#pragma unroll
+    for (int u = 0; u < NWT; ++u) {
+        const int idx = tid + NTHR * u;
+        const int q4 = idx % PPX, nl = (idx / PPX) % NTILE, tap = idx / (NTILE * PPX);
+        const int tsrc = WMODE == 0 ? tap : 8 - tap;
+        offw[u] = idx < NWTP ? (unsigned)((((tsrc * a.Cout + n0 + nl) * a.Cin) + 8 * q4) * (int)sizeof(bf16_t)) : DASR_OOB;
+    }
     auto prefetch = [&](int c0) {
+        const unsigned cb = (unsigned)c0 * (unsigned)sizeof(bf16_t);
 #pragma unroll
-        for (int u = 0; u < NIN; ++u) {
-            const int idx = tid + 256 * u;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (idx < NINP) {
-                const int pix = idx >> 2, q4 = idx & 3;
-                const int gy = y0 + pix / CB_HALO_W - 1, gx = x0 + pix % CB_HALO_W - 1;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *(const u32x4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 8 * q4);
-            }
-            pin[u] = v;
-        }
-        // kernel slice as [tap][n][k], k contiguous in both modes:
-        //   forward: second half of the packed kernel, [tap][co][ci];  dgrad: first half (HWIO = [tap][n = ci_f][k = co_f]),
-        //   taps flipped
+        for (int u = 0; u < NIN; ++u) pin[u] = dasr_buffer_load16(rx, offx[u] + cb);
 #pragma unroll
-        for (int u = 0; u < NWT; ++u) {
-            const int idx = tid + 256 * u;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (idx < NWTP) {
-                const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
-                const int tsrc = WMODE == 0 ? tap : 8 - tap;
-                v = *(const u32x4*)(wsrc + ((size_t)tsrc * a.Cout + n0 + nl) * a.Cin + c0 + 8 * q4);
-            }
-            pwt[u] = v;
-        }
+        for (int u = 0; u < NWT; ++u) pwt[u] = dasr_buffer_load16(rw, offw[u] + cb);
     };
+    // LDS images: piece idx of either tile goes to (idx / PPX) * CKP + 8 * (idx % PPX): a per-thread base plus a
+    // compile-time step per u
+    bf16_t* const lin = sIn + (tid / PPX) * CKP + 8 * (tid % PPX);
+    bf16_t* const lwt = sW + (tid / PPX) * CKP + 8 * (tid % PPX);
     auto commit = [&]() {
 #pragma unroll
-        for (int u = 0; u < NIN; ++u) {
-            const int idx = tid + 256 * u;
-            if (idx < NINP) *(u32x4*)(sIn + (idx >> 2) * CB_CKP + 8 * (idx & 3)) = pin[u];
-        }
+        for (int u = 0; u < NIN; ++u)
+            if ((u + 1) * NTHR <= NINP || tid + NTHR * u < NINP) *(u32x4*)(lin + u * (NTHR / PPX) * CKP) = pin[u];
 #pragma unroll
-        for (int u = 0; u < NWT; ++u) {
-            const int idx = tid + 256 * u;
-            if (idx < NWTP) {
-                const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
-                *(u32x4*)(sW + (tap * NTILE + nl) * CB_CKP + 8 * q4) = pwt[u];
-            }
-        }
+        for (int u = 0; u < NWT; ++u)
+            if ((u + 1) * NTHR <= NWTP || tid + NTHR * u < NWTP) *(u32x4*)(lwt + u * (NTHR / PPX) * CKP) = pwt[u];
     };
     prefetch(0);
-    for (int c0 = 0; c0 < a.Cin; c0 += CB_CK) {
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();                       // every wave is done reading the previous chunk
         commit();
         __syncthreads();
-        if (c0 + CB_CK < a.Cin) prefetch(c0 + CB_CK);
+        if (c0 + CK < a.Cin) prefetch(c0 + CK);
         // 9 taps x 2 K-steps of 16 channels; the operands of step j+1 are read while the MFMAs of step j run
+        constexpr int KS = CK / 16, NJ = 9 * KS;      // K steps of 16 channels per tap, fragment steps per chunk
         auto ldfrag = [&](int j, bf16x8 (&A)[CB_MTW], bf16x8 (&Bf)[NT]) {
-            const int tap = j >> 1, q = j & 1;
+            const int tap = j / KS, q = j % KS;
             const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
             for (int m = 0; m < CB_MTW; ++m)
-                A[m] = *(const bf16x8*)(sIn + ((CB_MTW * wv + m + dy) * CB_HALO_W + li + dx) * CB_CKP + 16 * q + 8 * lh);
+                A[m] = *(const bf16x8*)(sIn + ((CB_MTW * wv + m + dy) * CB_HALO_W + li + dx) * CKP + 16 * q + 8 * lh);
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                Bf[n] = *(const bf16x8*)(sW + (tap * NTILE + 32 * n + li) * CB_CKP + 16 * q + 8 * lh);
+                Bf[n] = *(const bf16x8*)(sW + (tap * NTILE + 32 * n + li) * CKP + 16 * q + 8 * lh);
         };
         auto mma = [&](const bf16x8 (&A)[CB_MTW], const bf16x8 (&Bf)[NT]) {
 #pragma unroll
@@ -144,14 +149,25 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_bf16(ConvBf16Args a) {
                 for (int n = 0; n < NT; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], Bf[n], acc[m][n], 0, 0, 0);
         };
-        bf16x8 A0[CB_MTW], B0[NT], A1[CB_MTW], B1[NT];
-        ldfrag(0, A0, B0);
+        if (NT * CB_MTW < 8) {
+            bf16x8 A0[CB_MTW], B0[NT], A1[CB_MTW], B1[NT];
+            ldfrag(0, A0, B0);
 #pragma unroll
-        for (int j = 0; j < 18; j += 2) {
-            ldfrag(j + 1, A1, B1);
-            mma(A0, B0);
-            if (j + 2 < 18) ldfrag(j + 2, A0, B0);
-            mma(A1, B1);
+            for (int j = 0; j < NJ; j += 2) {
+                if (j + 1 < NJ) ldfrag(j + 1, A1, B1);
+                mma(A0, B0);
+                if (j + 2 < NJ) ldfrag(j + 2, A0, B0);
+                if (j + 1 < NJ) mma(A1, B1);
+            }
+        } else {
+            // 128 accumulator registers: one fragment set (the SIMD's other wave covers the read latency)
+            bf16x8 A0[CB_MTW], B0[NT];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                ldfrag(j, A0, B0);
+                mma(A0, B0);
+                DASR_SCHED_BARRIER();      // keep the scheduler from hoisting later steps' reads (register budget)
+            }
         }
     }
 
@@ -262,30 +278,36 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_bf16(ConvBf16Args a) {
     }
 }
 
-static size_t conv_bf16_lds(int NT) {
-    const size_t main_b = sizeof(bf16_t) * (size_t)(CB_HALO_H * CB_HALO_W * CB_CKP + 9 * 32 * NT * CB_CKP);
-    const size_t ep_b = sizeof(float) * (size_t)(4 * 32 * (32 * NT + 4));
+static size_t conv_bf16_lds(int NT, int NW, int MTW, int CK) {
+    const size_t main_b = sizeof(bf16_t) * (size_t)((MTW * NW + 2) * CB_HALO_W * (CK + 8) + 9 * 32 * NT * (CK + 8));
+    const size_t ep_b = sizeof(float) * (size_t)(NW * 32 * (32 * NT + 4));
     return main_b > ep_b ? main_b : ep_b;
 }
 
 bool conv_bf16_supported(const ConvGeom& g) {
-    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin % CB_CK) == 0 &&
+    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin % 32) == 0 &&
            (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
 }
 bool conv_bf16_dgrad_supported(const ConvGeom& g) {
-    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cout % CB_CK) == 0 &&
+    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cout % 32) == 0 &&
            (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
 }
 
+// Tile variants measured on the MI355X at the x4 / B=32 shapes (tools/bench_ops_bf16.py, profiles/r02_conv_bf16_variants.txt):
+// 8-row tiles with two 256-thread workgroups per CU (NW = 4) beat one 512-thread workgroup with 16-row tiles (NW = 8) on
+// every shape but one (the two co-resident workgroups are out of step, so one's barriers and staging overlap the other's
+// MFMAs); four rows per wave (128 accumulators, 16-channel chunks) spills its epilogue and lost 2-3x.  So: NW = 4,
+// two rows per wave, 32-channel chunks.
 template <int WMODE>
 static int launch_conv_bf16(ConvBf16Args& a, void* stream) {
-    const bool nt2 = (a.Cout % 64) == 0;
-    const int tiles = ((a.W + CB_TW - 1) / CB_TW) * ((a.H + CB_TH - 1) / CB_TH);
+    const int NT = (a.Cout % 64) == 0 ? 2 : 1;
+    const int TH = 8;
+    const int tiles = ((a.W + CB_TW - 1) / CB_TW) * ((a.H + TH - 1) / TH);
     const int G8 = (tiles * a.B + 7) / 8 * 8;                 // pixel tiles, padded to whole rounds over the 8 XCDs
-    const dim3 grid(G8 * (a.Cout / (nt2 ? 64 : 32)));
-    const size_t lds = conv_bf16_lds(nt2 ? 2 : 1);
-    if (nt2) DASR_LAUNCH((k_conv3x3_bf16<2, WMODE>), grid, dim3(256), lds, stream, a);
-    else     DASR_LAUNCH((k_conv3x3_bf16<1, WMODE>), grid, dim3(256), lds, stream, a);
+    const dim3 grid(G8 * (a.Cout / (32 * NT)));
+    const size_t lds = conv_bf16_lds(NT, 4, 2, 32);
+    if (NT == 2) DASR_LAUNCH((k_conv3x3_bf16<2, WMODE, 4, 2, 32>), grid, dim3(256), lds, stream, a);
+    else         DASR_LAUNCH((k_conv3x3_bf16<1, WMODE, 4, 2, 32>), grid, dim3(256), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
 }
 
@@ -321,14 +343,16 @@ struct WgradBf16Args {
 template <int MT, int NTW>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_bf16(WgradBf16Args a) {
     DASR_DYN_SMEM(smem);
-    constexpr int CIG = 32 * MT, COG = 32 * NTW;
+    constexpr int CIG = 32 * MT, COG = 32 * NTW, NTHR = 256;
     constexpr int TH = wb_th(MT, NTW);
     constexpr int SXP = wb_stride(CIG), SDP = wb_stride(COG);
     constexpr int G = 4 / (MT * NTW);           // wave groups sharing one (mt, nt) pair, splitting the taps
     constexpr int NACC = (9 + G - 1) / G;
     bf16_t* sX = (bf16_t*)smem;                                   // [(TH+2)*(TW+2)][SXP]
     bf16_t* sD = sX + (TH + 2) * (WB_TW + 2) * SXP;               // [TH*TW][SDP]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // wave-uniform values in SGPRs: the tap split below branches on them around MFMAs, and an MFMA ignores EXEC - a
+    // condition the compiler believes to be per-lane would be "guarded" by an exec mask only
+    const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
     const int li = lane & 31, lh = lane >> 5;
     const int pair = wv % (MT * NTW), grp = wv / (MT * NTW);
     const int mt = pair / NTW, nt = pair % NTW;
@@ -352,43 +376,53 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_bf16(WgradBf16Args a) 
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
     const int xoff = 32 * mt + 16 * tg + 4 * tp, doff = 32 * nt + 16 * tg + 4 * tp;
 
+    // Staging addresses, computed once: piece u of this thread sits at a fixed byte offset from the tile's origin pixel
+    // (relx / reld), in a fixed tile column (colx / cold) and at a fixed LDS address; per tile only the origin changes.
+    // Rows outside the image fall outside the sample's buffer range (negative offsets wrap to >= 2^31) and load zeros by
+    // themselves; columns outside the image are turned into DASR_OOB by one compare.
+    constexpr int NX = (TH + 2) * (WB_TW + 2) * (CIG / 8), NXI = (NX + 255) / 256;
+    constexpr int ND = TH * WB_TW * (COG / 8), NDI = (ND + 255) / 256;
+    int relx[NXI], colx[NXI], reld[NDI], cold[NDI];
+    bf16_t* ldsx[NXI];
+    bf16_t* ldsd[NDI];
+#pragma unroll
+    for (int u = 0; u < NXI; ++u) {
+        const int idx = tid + 256 * u;
+        const int c8 = idx % (CIG / 8), pix = idx / (CIG / 8);
+        const int py = pix / (WB_TW + 2) - 1, px = pix % (WB_TW + 2) - 1;
+        relx[u] = ((py * a.W + px) * a.Cin + ci0 + 8 * c8) * (int)sizeof(bf16_t);
+        colx[u] = idx < NX ? px : -(1 << 20);                    // a column that is never inside the image
+        ldsx[u] = sX + pix * SXP + 8 * c8;
+    }
+#pragma unroll
+    for (int u = 0; u < NDI; ++u) {
+        const int idx = tid + 256 * u;
+        const int c8 = idx % (COG / 8), pix = idx / (COG / 8);
+        const int py = pix / WB_TW, px = pix % WB_TW;
+        reld[u] = ((py * a.W + px) * a.Cout + co0 + 8 * c8) * (int)sizeof(bf16_t);
+        cold[u] = idx < ND ? px : -(1 << 20);
+        ldsd[u] = sD + pix * SDP + 8 * c8;
+    }
     for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int x0 = tx * WB_TW, y0 = ty * TH;
-        constexpr int NX = (TH + 2) * (WB_TW + 2) * (CIG / 8), NXI = (NX + 255) / 256;
-        constexpr int ND = TH * WB_TW * (COG / 8), NDI = (ND + 255) / 256;
+        const BufRsrc rx = dasr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.Cin, (size_t)a.H * a.W * a.Cin * sizeof(bf16_t));
+        const BufRsrc rd = dasr_make_rsrc(a.dy + (size_t)b * a.H * a.W * a.Cout, (size_t)a.H * a.W * a.Cout * sizeof(bf16_t));
+        const int ox = (y0 * a.W + x0) * a.Cin * (int)sizeof(bf16_t), od = (y0 * a.W + x0) * a.Cout * (int)sizeof(bf16_t);
         u32x4 vx[NXI], vd[NDI];
 #pragma unroll
-        for (int u = 0; u < NXI; ++u) {
-            const int idx = tid + 256 * u;
-            const int c8 = idx % (CIG / 8), pix = idx / (CIG / 8);
-            const int gy = y0 + pix / (WB_TW + 2) - 1, gx = x0 + pix % (WB_TW + 2) - 1;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (idx < NX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = *(const u32x4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 8 * c8);
-            vx[u] = v;
-        }
+        for (int u = 0; u < NXI; ++u)
+            vx[u] = dasr_buffer_load16(rx, (unsigned)(x0 + colx[u]) < (unsigned)a.W ? (unsigned)(ox + relx[u]) : DASR_OOB);
 #pragma unroll
-        for (int u = 0; u < NDI; ++u) {
-            const int idx = tid + 256 * u;
-            const int c8 = idx % (COG / 8), pix = idx / (COG / 8);
-            const int gy = y0 + pix / WB_TW, gx = x0 + pix % WB_TW;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (idx < ND && gy < a.H && gx < a.W)
-                v = *(const u32x4*)(a.dy + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 8 * c8);
-            vd[u] = v;
-        }
+        for (int u = 0; u < NDI; ++u)
+            vd[u] = dasr_buffer_load16(rd, (unsigned)(x0 + cold[u]) < (unsigned)a.W ? (unsigned)(od + reld[u]) : DASR_OOB);
         __syncthreads();                        // every wave is done with the previous tile
 #pragma unroll
-        for (int u = 0; u < NXI; ++u) {
-            const int idx = tid + 256 * u;
-            if (idx < NX) *(u32x4*)(sX + (idx / (CIG / 8)) * SXP + 8 * (idx % (CIG / 8))) = vx[u];
-        }
+        for (int u = 0; u < NXI; ++u)
+            if ((u + 1) * 256 <= NX || tid + 256 * u < NX) *(u32x4*)ldsx[u] = vx[u];
 #pragma unroll
-        for (int u = 0; u < NDI; ++u) {
-            const int idx = tid + 256 * u;
-            if (idx < ND) *(u32x4*)(sD + (idx / (COG / 8)) * SDP + 8 * (idx % (COG / 8))) = vd[u];
-        }
+        for (int u = 0; u < NDI; ++u)
+            if ((u + 1) * 256 <= ND || tid + 256 * u < ND) *(u32x4*)ldsd[u] = vd[u];
         __syncthreads();
         if (do_bias) {                          // bias gradient: column sums of the staged dy tile
 #pragma unroll 8

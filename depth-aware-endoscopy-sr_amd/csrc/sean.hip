@@ -776,6 +776,255 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     }
 }
 
+// ---- backward, pass A, one-hot, bf16 activations --------------------------------------------------------------------
+// Same algorithm as k_sean_bwd_a_onehot, restructured for the bf16 path, where this kernel is the largest single item of
+// a training step (1.9 ms per launch at x4 / B=32 in the version above: a quarter of it the exact-fp32 MFMA phase, the
+// rest a memory phase with one 4-pixel step in flight per wave):
+//  * the segmented sum dD_tap = O_tap^T . G runs on v_mfma_f32_16x16x32_bf16 (K = 32 pixels per instruction instead of 4,
+//    at half the cycles): the one-hot operand is exact in bf16, G is stored in LDS in bf16 (its consumers, the
+//    gamma_s / beta_s kernels' gradients, are sums over ~10^5 pixels) and read with ds_read_b64_tr_b16 (a lane needs
+//    8 consecutive PIXELS of one channel);
+//  * phase 1 keeps all four 4-pixel steps of a tile in flight (unconditional clamped loads into registers), and the next
+//    tile's loads are issued before the matrix phase, so HBM latency hides under it and under the barriers.
+#define SB16_GST 160           // sG pixel stride in bf16 elements (320 B: the 4 pixel rows of a transposed read fall in
+                               // four disjoint 64-byte bank ranges)
+// Eight consecutive region bytes starting at an arbitrary (unaligned) LDS address, as two dwords: three aligned
+// ds_read_b32 and two v_alignbyte_b32.  (Written as eight byte reads, the compiler merges them into ONE ds_read_b64 of
+// unknown alignment, which does not return the bytes at the misaligned address on this hardware: the first GPU run of
+// this kernel had an O(1) error in dD that the CPU emulator could not show.)
+__device__ __forceinline__ void lds_ld8_unaligned(const unsigned char* p, unsigned& lo, unsigned& hi) {
+#if DASR_DEVICE_BUILD
+    const unsigned addr = (unsigned)(size_t)p, sh = addr & 3u;
+    const unsigned* q = (const unsigned*)(p - sh);
+    const unsigned w0 = q[0], w1 = q[1], w2 = q[2];
+    lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+#else
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+#endif
+}
+
+struct SeanBwdLoads {
+    bf16x4 g0[4], ov[4], tv[4], g2[4], b2[4];
+};
+
+__global__ void __launch_bounds__(512) k_sean_bwd_a_onehot_bf16(
+    SeanGeom g, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const bf16_t* __restrict__ t,
+    const float* __restrict__ mean, const float* __restrict__ var, const bf16_t* __restrict__ gb2,
+    const unsigned char* __restrict__ region, const int* __restrict__ flag, const float* __restrict__ D,
+    const float* __restrict__ bias_g, const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
+    const float* __restrict__ alpha_b, bf16_t* __restrict__ dt, bf16_t* __restrict__ dgb2, float* __restrict__ dD_slabs,
+    float* __restrict__ dbias_g, float* __restrict__ dbias_b, float* __restrict__ dalpha_g,
+    float* __restrict__ dalpha_b, bf16_t* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
+    if (flag && *flag != 0) return;
+    DASR_DYN_SMEM(smem);
+    const int K1 = g.K + 1;
+    float* sD = (float*)smem;                                   // [18][K+1][64]
+    bf16_t* sG = (bf16_t*)(sD + 18 * K1 * 64);                  // [SB_TH*SF_TW][SB16_GST]: gamma part | beta part
+    float* sred = (float*)(sG + SB_TH * SF_TW * SB16_GST);      // [8 waves][18][16] reduction scratch
+    unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);   // [(SB_TH+2)*(SF_TW+2)]
+    const int b = blockIdx.y, c0 = blockIdx.z * 64;
+    const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cq = lane & 15, ps = lane >> 4;
+    const bool live = c0 + 4 * cq < g.C;
+    const int c = live ? c0 + 4 * cq : 0;                       // dead lanes shadow channel 0 and never store
+    const float a_g = alpha_g[0], a_b = alpha_b[0];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 mu = zero4, sc = zero4, bg = zero4, bb = zero4;
+    if (live) {
+        mu = *(const float4*)(mean + (size_t)b * g.C + c);
+        const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
+        sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
+                         dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
+        bg = *(const float4*)(bias_g + c);
+        bb = *(const float4*)(bias_b + c);
+    }
+    float4 S1 = zero4, S2 = zero4, dbg = zero4, dbb = zero4;
+    float dag = 0.f, dab = 0.f;
+    f32x4 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = 0.f;
+    sean_stage_D(g, D, sD, b, c0);
+    const int mydy = wv / 3, mydx = wv % 3;     // tap of this wave (taps 0..7); tap 8 = (2,2) is shared
+    const int ly = wv >> 1;                     // phase 1: wave w -> tile row w>>1, columns 16*(w&1) .. +15
+    // unconditional loads of the tile's four 4-pixel steps (coordinates clamped into the image)
+    auto issue = [&](int tile, SeanBwdLoads& f) {
+        const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
+        const int y = imin(y0 + ly, g.H - 1);
+        const size_t row = ((size_t)b * g.H + y) * g.W;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = imin(x0 + 16 * (wv & 1) + 4 * u + ps, g.W - 1);
+            const size_t p = row + x;
+            f.g0[u] = *(const bf16x4*)(dout + p * g.C + c);
+            f.ov[u] = *(const bf16x4*)(out + p * g.C + c);
+            f.tv[u] = *(const bf16x4*)(t + p * g.C + c);
+            f.g2[u] = *(const bf16x4*)(gb2 + p * 2 * g.C + c);
+            f.b2[u] = *(const bf16x4*)(gb2 + p * 2 * g.C + g.C + c);
+        }
+    };
+    auto f4 = [](bf16x4 v) { return make_float4(dasr_bf2f(v[0]), dasr_bf2f(v[1]), dasr_bf2f(v[2]), dasr_bf2f(v[3])); };
+    SeanBwdLoads cur;
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x, cur);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
+        __syncthreads();                          // previous phase 2 is done with sG / sR
+        sean_stage_R(g, region, sR, b, y0, x0, SB_TH);
+        __syncthreads();
+        // ---- phase 1
+        {
+            const int y = y0 + ly;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int lx = 16 * (wv & 1) + 4 * u + ps, x = x0 + lx;
+                float4 G1 = zero4, B1 = zero4;
+                if (live && y < g.H && x < g.W) {
+                    const size_t p = ((size_t)b * g.H + y) * g.W + x;
+                    float4 g0 = f4(cur.g0[u]);
+                    if (relu) {
+                        const float4 ov = f4(cur.ov[u]);
+                        g0.x = ov.x > 0.f ? g0.x : 0.f; g0.y = ov.y > 0.f ? g0.y : 0.f;
+                        g0.z = ov.z > 0.f ? g0.z : 0.f; g0.w = ov.w > 0.f ? g0.w : 0.f;
+                    }
+                    if (dres) st4(dres + p * g.C + c, g0);
+                    const float4 tv = f4(cur.tv[u]), g2 = f4(cur.g2[u]), b2 = f4(cur.b2[u]);
+                    float4 g1, b1;
+                    sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
+                    const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
+                    const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
+                    const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
+                    st4(dgb2 + p * 2 * g.C + c, make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y,
+                                                            (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w));
+                    st4(dgb2 + p * 2 * g.C + g.C + c, make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y,
+                                                                  (1.f - a_b) * g0.z, (1.f - a_b) * g0.w));
+                    dag += dgam.x * (g1.x - g2.x) + dgam.y * (g1.y - g2.y) + dgam.z * (g1.z - g2.z) +
+                           dgam.w * (g1.w - g2.w);
+                    dab += g0.x * (b1.x - b2.x) + g0.y * (b1.y - b2.y) + g0.z * (b1.z - b2.z) + g0.w * (b1.w - b2.w);
+                    G1 = make_float4(a_g * dgam.x, a_g * dgam.y, a_g * dgam.z, a_g * dgam.w);
+                    B1 = make_float4(a_b * g0.x, a_b * g0.y, a_b * g0.z, a_b * g0.w);
+                    dbg = f4add(dbg, G1);
+                    dbb = f4add(dbb, B1);
+                    float4 dxh;
+                    dxh.x = g0.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x);
+                    dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
+                    dxh.z = g0.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z);
+                    dxh.w = g0.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w);
+                    st4(dt + p * g.C + c, dxh);
+                    S1 = f4add(S1, dxh);
+                    S2.x = fmaf(dxh.x, xc.x, S2.x); S2.y = fmaf(dxh.y, xc.y, S2.y);
+                    S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
+                }
+                bf16_t* gp = sG + (ly * SF_TW + lx) * SB16_GST + 4 * cq;
+                st4(gp, G1);                       // channels 0..63: gamma part
+                st4(gp + 64, B1);                  // channels 64..127: beta part
+                DASR_SCHED_BARRIER();              // one step's gather rows at a time (256-VGPR budget)
+            }
+        }
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, cur);    // in flight during the matrix phase
+        __syncthreads();
+        // ---- phase 2: one-hot(region) x G, 32 pixels per MFMA (one tile row per K step)
+        {
+            const int i16 = lane & 15, kg = lane >> 4;            // A: region row i16, pixels 8*kg .. 8*kg+7 of the step
+            const int tq = (lane & 15) >> 2, tp = lane & 3;       // transposed-read role inside the 16-lane group
+#pragma unroll
+            for (int s = 0; s < SB_TH; ++s) {
+                unsigned my_lo, my_hi, t8_lo, t8_hi;
+                lds_ld8_unaligned(sR + (s + mydy) * (SF_TW + 2) + 8 * kg + mydx, my_lo, my_hi);
+                lds_ld8_unaligned(sR + (s + 2) * (SF_TW + 2) + 8 * kg + 2, t8_lo, t8_hi);
+                bf16x8 a_my, a_8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a_my[j] = dasr_f2bf((int)((my_lo >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
+                    a_my[4 + j] = dasr_f2bf((int)((my_hi >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
+                    a_8[j] = dasr_f2bf((int)((t8_lo >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
+                    a_8[4 + j] = dasr_f2bf((int)((t8_hi >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
+                }
+                const bf16_t* gq = sG + (s * SF_TW + 8 * kg + tq) * SB16_GST + 4 * tp;
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    const bf16x4 lo = lds_read_tr16(gq + 16 * nt), hi = lds_read_tr16(gq + 16 * nt + 4 * SB16_GST);
+                    bf16x8 bv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = lo[e]; bv[4 + e] = hi[e]; }
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_my, bv, acc[nt], 0, 0, 0);
+                }
+                // tap 8, N-tile `wv`: its own operand reads and an UNCONDITIONAL MFMA.  (An MFMA ignores EXEC: written
+                // as `if (nt == wv) acc[8] = mfma(...)` inside the loop above, hipcc guards it with s_and_saveexec on the
+                // per-lane compare and no branch, so every wave executed all eight of them - wrong on the GPU, right on
+                // the CPU emulator.  Never put an MFMA under a condition that lives in a VGPR.)
+                {
+                    const bf16x4 lo = lds_read_tr16(gq + 16 * wv), hi = lds_read_tr16(gq + 16 * wv + 4 * SB16_GST);
+                    bf16x8 bv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = lo[e]; bv[4 + e] = hi[e]; }
+                    acc[8] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_8, bv, acc[8], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- per-channel sums: reduce over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
+    float vals[18] = {S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, dbg.x, dbg.y, dbg.z, dbg.w,
+                      dbb.x, dbb.y, dbb.z, dbb.w, dag, dab};
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+        vals[q] += __shfl_xor(vals[q], 16, 64);
+        vals[q] += __shfl_xor(vals[q], 32, 64);
+    }
+    __syncthreads();
+    if (ps == 0) {
+#pragma unroll
+        for (int q = 0; q < 18; ++q) sred[(wv * 18 + q) * 16 + cq] = vals[q];
+    }
+    __syncthreads();
+    if (wv == 0 && ps == 0) {
+        float r[18];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            r[q] = 0.f;
+            for (int w = 0; w < 8; ++w) r[q] += sred[(w * 18 + q) * 16 + cq];
+        }
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(&S[((size_t)b * g.C + c + j) * 2 + 0], r[j]);
+                atomicAdd(&S[((size_t)b * g.C + c + j) * 2 + 1], r[4 + j]);
+                atomicAdd(&dbias_g[c + j], r[8 + j]);
+                atomicAdd(&dbias_b[c + j], r[12 + j]);
+            }
+        }
+        float ra = live ? r[16] : 0.f, rb = live ? r[17] : 0.f;
+        for (int off = 8; off > 0; off >>= 1) {
+            ra += __shfl_xor(ra, off, 64);
+            rb += __shfl_xor(rb, off, 64);
+        }
+        if (cq == 0) {
+            atomicAdd(dalpha_g, ra);
+            atomicAdd(dalpha_b, rb);
+        }
+    }
+    // ---- slab [b][blockIdx.x][18][K][C]: D fragment of the 16x16 MFMA: column = lane&15 (channel within the N-tile),
+    // row = 4*(lane>>4) + reg (region index)
+    float* slab = dD_slabs + ((size_t)b * gridDim.x + blockIdx.x) * 18 * g.K * g.C;
+    {
+        const int j = lane & 15;
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) {
+            const int tap = nt < 8 ? wv : 8;
+            const int ntile = nt < 8 ? nt : wv;            // 0..7: gamma channels 0..63 then beta channels 0..63
+            const int s = ntile >> 2, cc = c0 + 16 * (ntile & 3) + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * (lane >> 4) + r;
+                if (k < g.K && cc < g.C) slab[((size_t)(s * 9 + tap) * g.K + k) * g.C + cc] = acc[nt][r];
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sean_dD_reduce(const float* __restrict__ slabs, const int* __restrict__ flag,
                                                         float* __restrict__ dD, int per_sample, int nslab, size_t n) {
     if (flag && *flag != 0) return;
@@ -920,9 +1169,18 @@ static int sean_bwd_impl(const T* dout, const T* out, const T* t, const float* m
         int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SB_TH - 1) / SB_TH);
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64 + SB_TH * SF_TW * SB_GST + 8 * 18 * 16) +
                      (SB_TH + 2) * (SF_TW + 2);
-        DASR_LAUNCH((k_sean_bwd_a_onehot<T>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t, mean,
-                    var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
-                    dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
+        if (sizeof(T) == 2) {
+            const size_t lds16 = sizeof(float) * (size_t)(18 * (K + 1) * 64 + 8 * 18 * 16) +
+                                 sizeof(bf16_t) * (size_t)(SB_TH * SF_TW * SB16_GST) + (SB_TH + 2) * (SF_TW + 2) + 8;
+            DASR_LAUNCH(k_sean_bwd_a_onehot_bf16, dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds16, stream, g,
+                        (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)t, mean, var, (const bf16_t*)gb2, region,
+                        onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, (bf16_t*)dt, (bf16_t*)dgb2, slabs, dbias_g, dbias_b,
+                        dalpha_g, dalpha_b, (bf16_t*)dres, S, relu, eps, ntiles);
+        } else {
+            DASR_LAUNCH((k_sean_bwd_a_onehot<T>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
+                        mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
+                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
+        }
         size_t n = (size_t)B * 18 * K * C;
         DASR_LAUNCH(k_sean_dD_reduce, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, (const float*)slabs, onehot_flag, dD,
                     18 * K * C, nblk, n);

@@ -181,6 +181,30 @@ static inline f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
+// v_mfma_f32_16x16x32_bf16: A lane l holds A[row l&15][k = 8(l>>4) + j], B lane holds B[k = 8(l>>4) + j][col l&15];
+// C/D: col = lane&15, row = 4*(lane>>4) + reg
+static inline f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, f32x4 c, int, int, int) {
+    char* buf = (char*)hipemu::wave_buf();
+    int l = hipemu::lane_id();
+    memcpy(buf + 64 * l, &a, 16);
+    memcpy(buf + 64 * l + 16, &b, 16);
+    hipemu::wave_barrier();
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            __bf16 av, bv;
+            memcpy(&av, buf + 64 * (row + 16 * (k >> 3)) + 2 * (k & 7), 2);
+            memcpy(&bv, buf + 64 * (col + 16 * (k >> 3)) + 16 + 2 * (k & 7), 2);
+            acc = fmaf(hipemu_bf2f(av), hipemu_bf2f(bv), acc);
+        }
+        c[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_f32_16x16x32_bf16
 
 // ---- ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per group of 16 consecutive lanes, lane 4q+p supplies the address
 // of row q, columns 4p..4p+3 of a 4 x 16 block of 16-bit elements; lane i of the group receives column i, row q in its
