@@ -61,6 +61,18 @@ def main():
         us = timeit(lambda: ops.sean_bwd(dout, out, t, mean, var, gb2, mk, region, flag, D, bg, bb, ag, ab, True, True),
                     a.iters)
         print("sean_bwd (fast)           %8.1f us  %7.1f GB/s (12C floats/px)" % (us, px * 12 * C * 4 / us / 1e3))
+    if not a.only or "dynk" in a.only:
+        L = 256
+        st = torch.randn(B, K, L, device=dev)
+        A_w, A_b = torch.randn(K, K, 1, 1, device=dev) * 0.3, torch.randn(K, device=dev) * 0.1
+        Wg, Wb = torch.randn(C, L, 3, 3, device=dev) * 0.05, torch.randn(C, L, 3, 3, device=dev) * 0.05
+        stp, Dk = ops.dynk_fwd(st, A_w, A_b, Wg, Wb)
+        dD = torch.randn_like(Dk)
+        dst = torch.zeros_like(st)
+        us = timeit(lambda: ops.dynk_fwd(st, A_w, A_b, Wg, Wb), a.iters)
+        print("dynk_fwd (stp + D)        %8.1f us" % us)
+        us = timeit(lambda: ops.dynk_bwd(dD, st, stp, A_w, Wg, Wb, dst), a.iters)
+        print("dynk_bwd (dW, dstp, dA+dst: 3 launches) %8.1f us" % us)
     if not a.only or "conv" in a.only:
         shapes = [(128, 160, 64, 64), (128, 160, 128, 128), (128, 160, 32, 64), (128, 160, 64, 256),
                   (256, 320, 64, 32), (256, 320, 32, 32), (256, 320, 32, 128), (512, 640, 32, 32), (512, 640, 32, 128)]

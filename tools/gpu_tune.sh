@@ -1,4 +1,5 @@
-O=gpurun_out/r2f; mkdir -p $O
-python -m pytest tests/test_gpu_parity.py -q -x -k "bf16" -s 2>&1 | grep -v "^$" | tail -6 | cut -c1-900
-python tools/bench_ops_bf16.py --only sean > $O/sean.txt 2>&1; cat $O/sean.txt
-for v in "4 2" "8 2" "8 4"; do set -- $v; echo "== NW=$1 MTW=$2"; DASR_CB_NW=$1 DASR_CB_MTW=$2 python tools/bench_ops_bf16.py --only conv 2>&1 | grep conv3x3 | tee -a $O/conv_variants.txt; done
+O=gpurun_out/r2h; mkdir -p $O
+python tools/bench_ops.py --batch 16 > $O/ops_b16.txt 2>&1; cat $O/ops_b16.txt
+python tools/bench_ops.py --batch 32 --only sean,dynk > $O/ops_b32_sean.txt 2>&1; cat $O/ops_b32_sean.txt
+python tools/bench_ops_bf16.py > $O/ops_bf16_c3.txt 2>&1; cat $O/ops_bf16_c3.txt
+python bench.py --batch 32 --no-cpu-baseline --no-b32 > $O/bench_batch32.json 2> $O/bench_batch32.err; cat $O/bench_batch32.json | cut -c1-400

@@ -19,8 +19,13 @@ if not csvs:
     sys.exit("no kernel trace csv under " + d)
 rows = [r for r in csv.DictReader(open(csvs[0])) if "k_sean_fwd_onehot" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-dur = [((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, "true>" in r["Kernel_Name"].split("(")[0])
-       for r in rows]
+def has_residual(name):
+    """k_sean_fwd_onehot<RELU, HAS_RES[, T]>: the second template argument."""
+    args = name.split("<", 1)[1].split(">", 1)[0].split(",")
+    return args[1].strip() in ("true", "1")
+
+
+dur = [((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, has_residual(r["Kernel_Name"])) for r in rows]
 nA = 26 * (warmup + steps)
 phases = {"overlapped_steps_b16": dur[:nA], "unoverlapped_step_b16": dur[nA:nA + 26],
           "forward_only_b32": dur[nA + 26 + 26:nA + 26 + 26 * 4]}      # first B=32 pass is the warm-up
@@ -38,8 +43,8 @@ def summarise(sel, B):
         true_b = (4 * (4 * C + (C if res else 0)) + 1) * B * PX
         out["residual" if res else "no_residual"] = {
             "launches": len(t), "avg_us": round(us, 2), "min_us": round(min(t), 2),
-            "frac_of_8TBs_survey_8d_bytes": round(alg / us / 1e6 / 8000.0, 4),
-            "frac_of_8TBs_kernel_minimum_bytes": round(true_b / us / 1e6 / 8000.0, 4)}
+            "frac_of_8TBs_survey_8d_bytes": round(alg / us / 1e3 / 8000.0, 4),        # bytes / us / 1e3 = GB/s
+            "frac_of_8TBs_kernel_minimum_bytes": round(true_b / us / 1e3 / 8000.0, 4)}
     if sel:
         out["avg_us_all"] = round(sum(x for x, _ in sel) / len(sel), 2)
     return out
