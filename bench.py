@@ -36,13 +36,20 @@ CONFIGS = {
     "c2": dict(scale=8, lr_hw=(128, 160), batch=16, dtype="f32",
                workload="Kvasir x8 synthetic, batch=%d per GPU, fp32, DepthNet nb=16 nf=64 L=256 K=10 (BASELINE.json "
                         "configs[1]); step = fwd + L1 + dynamic loss + bwd + Adam"),
+    "c4": dict(scale=8, lr_hw=(128, 160), batch=16, dtype="bf16",
+               workload="Kvasir x8 synthetic, batch=%d per GPU (BASELINE.json configs[3]: 128 over 8 GPUs), bf16 activations + "
+                        "bf16-MFMA trunk convs (fp32 master weights / statistics / accumulators), DepthNet nb=16 nf=64 L=256 "
+                        "K=10; step = fwd + L1 + dynamic loss + bwd + Adam"),
+    "c5": dict(scale=2, lr_hw=(1080, 1920), batch=1, dtype="f32", which=list(range(16)),
+               workload="EndoScene x2 synthetic, batch=%d per GPU (BASELINE.json configs[4]: 8 over 8 GPUs), one 1080x1920 LR "
+                        "frame, fp32, DepthNet nb=16 nf=64 L=256 K=10, DGBs 0..15; step = fwd + L1 + dynamic loss + bwd + Adam"),
     "c3": dict(scale=4, lr_hw=(256, 320), batch=32, dtype="bf16",
                workload="Kvasir x4 synthetic, batch=%d per GPU, bf16 activations + bf16-MFMA trunk convs (fp32 master "
                         "weights / statistics / accumulators), DepthNet nb=16 nf=64 L=256 K=10, LR 256x320 (BASELINE.json "
                         "configs[2]); step = fwd + L1 + dynamic loss + bwd + Adam"),
 }
 # algorithmic FLOPs of the trunk per frame, forward + backward
-TRUNK_GFLOP_PER_FRAME = {"c2": 848.0, "c3": 2685.0}
+TRUNK_GFLOP_PER_FRAME = {"c2": 848.0, "c3": 2685.0, "c4": 848.0}
 
 
 def sean_algorithmic_bytes(B, H, W, C, K, residual):
@@ -135,8 +142,8 @@ class ConvTimer:
         g.ops.conv2d_fwd = timed
 
 
-def mfma_roofline(net, args, B, elapsed, timer_conv):
-    """c3 (bf16): the step is bound by the bf16 matrix cores.  `achieved` = algorithmic FLOPs of one launch of the
+def mfma_roofline(net, args, B, elapsed, timer_conv, config):
+    """bf16 configs (c3, c4): the step is bound by the bf16 matrix cores.  `achieved` = algorithmic FLOPs of one launch of the
     dominant kernel (k_conv3x3_bf16 on the 128 -> 128 gamma_o|beta_o convolution, 2*9*128*128 FLOP per pixel) / its
     average launch duration, measured with HIP events in one extra un-overlapped forward after the timed region; the
     whole step's trunk FLOPs (2685 GFLOP per frame fwd+bwd) over the step time are reported next to it."""
@@ -159,13 +166,13 @@ def mfma_roofline(net, args, B, elapsed, timer_conv):
     flops = timer_conv.pairs[0][2]
     avg_ms = sum(ms) / len(ms)
     ach = flops / (avg_ms * 1e-3) / 1e12
-    step_tf = TRUNK_GFLOP_PER_FRAME["c3"] * 1e9 * B * args.steps / elapsed / 1e12
+    step_tf = TRUNK_GFLOP_PER_FRAME[config] * 1e9 * B * args.steps / elapsed / 1e12
     return {"bound": "mfma", "kernel": "k_conv3x3_bf16<NT=2> (dasr_conv2d_fwd_bf16, 128->128 gamma_o|beta_o conv, forward)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFS, 4),
             "traffic": None, "launches_timed": len(ms), "avg_launch_us": round(avg_ms * 1e3, 2),
             "algorithmic_flops_per_launch": flops,
             "measured": "HIP events on the launch stream, one un-overlapped forward pass after the timed region",
-            "whole_step": {"trunk_gflop_per_frame_fwd_bwd": TRUNK_GFLOP_PER_FRAME["c3"], "achieved_tflops": round(step_tf, 1),
+            "whole_step": {"trunk_gflop_per_frame_fwd_bwd": TRUNK_GFLOP_PER_FRAME[config], "achieved_tflops": round(step_tf, 1),
                            "frac_of_bf16_mfma_peak": round(step_tf / MFMA_BF16_PEAK_TFS, 4),
                            "note": "the 9x9 output conv and the fp32 encoder run on the fp32 matrix cores; SEAN, "
                                    "statistics and epilogue-backward kernels are HBM-bound"}}
@@ -245,7 +252,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json config (default c2 = configs[1])")
-    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: c2 16, c3 32)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: c2 16, c3 32, c4 16, c5 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the forward-only batch-32 roofline pass")
     args = ap.parse_args()
@@ -270,6 +277,8 @@ def main():
     global LR_H, LR_W, SCALE
     (LR_H, LR_W), SCALE = cfg["lr_hw"], cfg["scale"]
     opt = {"network_G": dict(networks.X8_NETWORK_G, upscale=SCALE), "datasets": {"train": {"depthMaskNum": K_REGIONS}}}
+    if "which" in cfg:
+        opt["network_G"]["which_ResBlk_depth"] = list(cfg["which"])
     net = networks.define_G(opt)
     synth.closed_form_fill_(net.state_dict().items())
     net = net.to(dev)
@@ -290,7 +299,7 @@ def main():
     timer = SeanTimer()
     timer.install()
     timer_conv = ConvTimer()
-    if args.config == "c3":
+    if cfg["dtype"] == "bf16":
         timer_conv.install()
 
     def barrier():
@@ -421,8 +430,8 @@ def main():
                     pass
         del lq32, dm32, mk32
 
-    if args.config == "c3":
-        roof = mfma_roofline(net, args, B, elapsed, timer_conv)
+    if cfg["dtype"] == "bf16":
+        roof = mfma_roofline(net, args, B, elapsed, timer_conv, args.config)
 
     if rank == 0:
         out = {

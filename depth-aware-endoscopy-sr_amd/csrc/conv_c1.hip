@@ -78,18 +78,20 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restric
         if (pl >= npl) continue;
         const T* grow = dy + ((size_t)row * W) * Cout + 4 * q;
         const T* arow = yact ? yact + ((size_t)row * W) * Cout + 4 * q : nullptr;
-        for (int px0 = pl; px0 < W; px0 += 4 * npl) {
-            // four pixels per trip: all eight 16-byte loads are issued before the first is consumed (clamped
-            // addresses, contributions of pixels past the row end are zeroed)
-            float4 gq[4], yq[4];
+        // NPX pixels per trip: all 2*NPX loads are issued before the first is consumed (clamped addresses, contributions of
+        // pixels past the row end are zeroed).  bf16 loads carry half the bytes, so twice the pixels keep the same bytes
+        // in flight (0.56 -> see DESIGN section 4 for the measured rates)
+        constexpr int NPX = sizeof(T) == 2 ? 8 : 4;
+        for (int px0 = pl; px0 < W; px0 += NPX * npl) {
+            float4 gq[NPX], yq[NPX];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NPX; ++u) {
                 const int px = px0 + u * npl < W ? px0 + u * npl : W - 1;
                 gq[u] = ld4(grow + (size_t)px * Cout);
                 yq[u] = arow ? ld4(arow + (size_t)px * Cout) : make_float4(1.f, 1.f, 1.f, 1.f);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NPX; ++u) {
                 const int px = px0 + u * npl;
                 float4 g = gq[u];
                 if (px >= W) g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -153,7 +155,8 @@ static int conv_c1_wgrad_impl(const ConvGeom& g, const float* x, const T* dy, co
     // one launch clears both accumulators (two memsets were two more dispatches on a 130 us kernel)
     DASR_LAUNCH(k_c1_zero, dim3(dasr_cdiv((size_t)10 * g.Cout, 256)), dim3(256), 0, stream, dw, 9 * g.Cout, dbias, g.Cout);
     unsigned grid = (unsigned)(g.B * g.H);
-    if (grid > 512) grid = 512;         // two workgroups per CU; more only adds float atomics at the end (measured)
+    const unsigned cap = sizeof(T) == 2 ? 768 : 512;   // fp32: two workgroups per CU (more only adds float atomics at the end, measured); bf16: three
+    if (grid > cap) grid = cap;
     DASR_LAUNCH((k_conv3x3_c1_wgrad<T>), dim3(grid), dim3(256), sizeof(float) * (256 * 40 + 3 * (g.W + 2)), stream, x, dy, yact,
                 dw, dbias, g.B, g.H, g.W, g.Cout, act);
     DASR_RETURN_LAUNCH_STATUS();

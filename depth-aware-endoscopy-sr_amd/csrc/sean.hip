@@ -589,203 +589,26 @@ __global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const TA
 // ---- backward, pass A, one-hot -------------------------------------------------------------------------
 // The dynamic-kernel gradient  dD[s][tap][k][c] = sum_p [r(p+tap) == k] * G_s[p][c],  G = (a_g*dgamma, a_b*dbeta),
 // is a segmented reduction by region.  LDS float atomics are far too slow for it on gfx950 (measured ~3 cycles
-// per LANE), so it runs on the matrix cores instead: per tap, dD_tap = O_tap^T . G with O_tap the pixels x regions
-// one-hot matrix (built on the fly from the region bytes) — v_mfma_f32_16x16x4_f32 with M = region (<= 16),
-// N = 16 channels, K = 4 pixels.
+// per LANE), so it runs on the matrix cores: per tap, dD_tap = O_tap^T . G with O_tap the pixels x regions one-hot
+// matrix (built on the fly from the region bytes), M = region (<= 16), N = 16 channels, K = pixels.
 //
-// Workgroup = 512 threads (8 waves), tile = 4 rows x 32 columns, persistent over the tiles of ONE sample.
+// Workgroup = 512 threads (8 waves), tile = SB_TH<T> rows x 32 columns, persistent over the tiles of ONE sample.
 //   phase 1 (all waves, elementwise): everything per pixel (dgb2, dres, dxhat -> dt, the per-channel sums) and
-//            G -> LDS tile sG [128 px][128 ch] (row stride 144 floats: conflict-free ds_read_b32 of the B operand)
-//   phase 2 (matrix cores): wave w accumulates tap w for all 128 channels (8 N-tiles) and N-tile w of tap 8:
-//            9 accumulators of 4 VGPRs, resident for the whole kernel.
+//            G -> LDS tile sG [pixels][128 ch] in bf16.  All of a tile's 4-pixel steps are in flight together
+//            (unconditional clamped loads into registers) and the NEXT tile's loads are issued before the matrix phase,
+//            so HBM latency hides under it and under the barriers.
+//   phase 2 (matrix cores, v_mfma_f32_16x16x32_bf16: K = 32 pixels per instruction): wave w accumulates tap w for all
+//            128 channels (8 N-tiles) and N-tile w of tap 8: 9 accumulators of 4 VGPRs, resident for the whole kernel.
+//            The one-hot operand is exact in bf16; the G operand is read with ds_read_b64_tr_b16 (a lane needs 8
+//            consecutive PIXELS of one channel).  bf16 activations: G is rounded to bf16 once (its consumers, the
+//            gamma_s / beta_s gradients, are sums over ~10^5 pixels).  fp32 activations: G is split into THREE bf16
+//            pieces (hi, mid, lo: 3 x 8 = 24 mantissa bits, each residual exact), three MFMAs per step - every product
+//            with a one-hot factor is exact, the accumulation is fp32, so the result is an fp32 sum in a different order;
+//            5x fewer matrix-pipe cycles than the v_mfma_f32_16x16x4_f32 version this replaces (80 of its 300 us).
 // At the end each workgroup writes its dD as a slab; k_sean_dD_reduce sums the slabs in a fixed order.
-#define SB_TH 4
-#define SB_GST 144
-
-template <typename T>
-__global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
-    SeanGeom g, const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ t,
-    const float* __restrict__ mean, const float* __restrict__ var, const T* __restrict__ gb2,
-    const unsigned char* __restrict__ region, const int* __restrict__ flag, const float* __restrict__ D,
-    const float* __restrict__ bias_g, const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
-    const float* __restrict__ alpha_b, T* __restrict__ dt, T* __restrict__ dgb2, float* __restrict__ dD_slabs,
-    float* __restrict__ dbias_g, float* __restrict__ dbias_b, float* __restrict__ dalpha_g,
-    float* __restrict__ dalpha_b, T* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
-    if (flag && *flag != 0) return;
-    DASR_DYN_SMEM(smem);
-    const int K1 = g.K + 1;
-    float* sD = (float*)smem;                                   // [18][K+1][64]
-    float* sG = sD + 18 * K1 * 64;                              // [SB_TH*SF_TW][SB_GST]
-    float* sred = sG + SB_TH * SF_TW * SB_GST;                  // [8 waves][18][16] reduction scratch
-    unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);   // [(SB_TH+2)*(SF_TW+2)]
-    const int b = blockIdx.y, c0 = blockIdx.z * 64;
-    const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int cq = lane & 15, ps = lane >> 4;
-    const int c = c0 + 4 * cq;
-    const bool live = c < g.C;
-    const float a_g = alpha_g[0], a_b = alpha_b[0];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 mu = zero4, sc = zero4, bg = zero4, bb = zero4;
-    if (live) {
-        mu = *(const float4*)(mean + (size_t)b * g.C + c);
-        const float4 vr = *(const float4*)(var + (size_t)b * g.C + c);
-        sc = make_float4(dasr_double_in_scale(vr.x, eps), dasr_double_in_scale(vr.y, eps),
-                         dasr_double_in_scale(vr.z, eps), dasr_double_in_scale(vr.w, eps));
-        bg = *(const float4*)(bias_g + c);
-        bb = *(const float4*)(bias_b + c);
-    }
-    float4 S1 = zero4, S2 = zero4, dbg = zero4, dbb = zero4;
-    float dag = 0.f, dab = 0.f;
-    f32x4 acc[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[q][r] = 0.f;
-    sean_stage_D(g, D, sD, b, c0);
-    const int mydy = wv / 3, mydx = wv % 3;     // tap of this wave (taps 0..7); tap 8 = (2,2) is shared
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
-        __syncthreads();                          // previous phase 2 is done with sG / sR
-        sean_stage_R(g, region, sR, b, y0, x0, SB_TH);
-        __syncthreads();
-        // ---- phase 1: wave w -> row w>>1, columns 16*(w&1) .. +15, four 4-pixel steps
-        {
-            const int ly = wv >> 1, y = y0 + ly;
-#pragma unroll 1
-            for (int u = 0; u < 4; ++u) {
-                const int lx = 16 * (wv & 1) + 4 * u + ps, x = x0 + lx;
-                float4 G1 = zero4, B1 = zero4;
-                if (live && y < g.H && x < g.W) {
-                    const size_t p = ((size_t)b * g.H + y) * g.W + x;
-                    float4 g0 = ld4(dout + p * g.C + c);
-                    if (relu) {
-                        const float4 ov = ld4(out + p * g.C + c);
-                        g0.x = ov.x > 0.f ? g0.x : 0.f; g0.y = ov.y > 0.f ? g0.y : 0.f;
-                        g0.z = ov.z > 0.f ? g0.z : 0.f; g0.w = ov.w > 0.f ? g0.w : 0.f;
-                    }
-                    if (dres) st4(dres + p * g.C + c, g0);
-                    const float4 tv = ld4(t + p * g.C + c);
-                    const float4 g2 = ld4(gb2 + p * 2 * g.C + c);
-                    const float4 b2 = ld4(gb2 + p * 2 * g.C + g.C + c);
-                    float4 g1, b1;
-                    sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
-                    const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
-                    const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
-                    const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
-                    st4(dgb2 + p * 2 * g.C + c, make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y,
-                                                            (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w));
-                    st4(dgb2 + p * 2 * g.C + g.C + c, make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y,
-                                                                  (1.f - a_b) * g0.z, (1.f - a_b) * g0.w));
-                    dag += dgam.x * (g1.x - g2.x) + dgam.y * (g1.y - g2.y) + dgam.z * (g1.z - g2.z) +
-                           dgam.w * (g1.w - g2.w);
-                    dab += g0.x * (b1.x - b2.x) + g0.y * (b1.y - b2.y) + g0.z * (b1.z - b2.z) + g0.w * (b1.w - b2.w);
-                    G1 = make_float4(a_g * dgam.x, a_g * dgam.y, a_g * dgam.z, a_g * dgam.w);
-                    B1 = make_float4(a_b * g0.x, a_b * g0.y, a_b * g0.z, a_b * g0.w);
-                    dbg = f4add(dbg, G1);
-                    dbb = f4add(dbb, B1);
-                    float4 dxh;
-                    dxh.x = g0.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x);
-                    dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
-                    dxh.z = g0.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z);
-                    dxh.w = g0.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w);
-                    st4(dt + p * g.C + c, dxh);
-                    S1 = f4add(S1, dxh);
-                    S2.x = fmaf(dxh.x, xc.x, S2.x); S2.y = fmaf(dxh.y, xc.y, S2.y);
-                    S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
-                }
-                float* gp = sG + (ly * SF_TW + lx) * SB_GST + 4 * cq;
-                *(float4*)gp = G1;                 // channels 0..63: gamma part
-                *(float4*)(gp + 64) = B1;          // channels 64..127: beta part
-            }
-        }
-        __syncthreads();
-        // ---- phase 2: one-hot(region) x G on the matrix cores; 4 pixels per MFMA step
-        {
-            const int i16 = lane & 15, k4 = lane >> 4;
-#pragma unroll 8
-            for (int s = 0; s < SB_TH * SF_TW / 4; ++s) {
-                const int q = 4 * s + k4;                     // tile-local pixel of this lane's K slot
-                const int ly = q / SF_TW, lx = q % SF_TW;
-                const float a_my = (sR[(ly + mydy) * (SF_TW + 2) + lx + mydx] == i16) ? 1.f : 0.f;
-                const float a_8 = (sR[(ly + 2) * (SF_TW + 2) + lx + 2] == i16) ? 1.f : 0.f;
-                const float* gq = sG + q * SB_GST + i16;
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_my, gq[16 * nt], acc[nt], 0, 0, 0);
-                acc[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_8, gq[16 * wv], acc[8], 0, 0, 0);
-            }
-        }
-    }
-    // ---- per-channel sums: reduce over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
-    float vals[18] = {S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, dbg.x, dbg.y, dbg.z, dbg.w,
-                      dbb.x, dbb.y, dbb.z, dbb.w, dag, dab};
-#pragma unroll
-    for (int q = 0; q < 18; ++q) {
-        vals[q] += __shfl_xor(vals[q], 16, 64);
-        vals[q] += __shfl_xor(vals[q], 32, 64);
-    }
-    __syncthreads();
-    if (ps == 0) {
-#pragma unroll
-        for (int q = 0; q < 18; ++q) sred[(wv * 18 + q) * 16 + cq] = vals[q];
-    }
-    __syncthreads();
-    if (wv == 0 && ps == 0) {
-        float r[18];
-#pragma unroll
-        for (int q = 0; q < 18; ++q) {
-            r[q] = 0.f;
-            for (int w = 0; w < 8; ++w) r[q] += sred[(w * 18 + q) * 16 + cq];
-        }
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                atomicAdd(&S[((size_t)b * g.C + c + j) * 2 + 0], r[j]);
-                atomicAdd(&S[((size_t)b * g.C + c + j) * 2 + 1], r[4 + j]);
-                atomicAdd(&dbias_g[c + j], r[8 + j]);
-                atomicAdd(&dbias_b[c + j], r[12 + j]);
-            }
-        }
-        float ra = r[16], rb = r[17];
-        for (int off = 8; off > 0; off >>= 1) {
-            ra += __shfl_xor(ra, off, 64);
-            rb += __shfl_xor(rb, off, 64);
-        }
-        if (cq == 0) {
-            atomicAdd(dalpha_g, ra);
-            atomicAdd(dalpha_b, rb);
-        }
-    }
-    // ---- slab [b][blockIdx.x][18][K][C]: D fragment of the 16x16x4 MFMA: column = lane&15 (channel within the
-    // N-tile), row = 4*(lane>>4) + reg (region index)
-    float* slab = dD_slabs + ((size_t)b * gridDim.x + blockIdx.x) * 18 * g.K * g.C;
-    {
-        const int j = lane & 15;
-#pragma unroll
-        for (int nt = 0; nt < 9; ++nt) {
-            const int tap = nt < 8 ? wv : 8;
-            const int ntile = nt < 8 ? nt : wv;            // 0..7: gamma channels 0..63 then beta channels 0..63
-            const int s = ntile >> 2, cc = c0 + 16 * (ntile & 3) + j;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = 4 * (lane >> 4) + r;
-                if (k < g.K && cc < g.C) slab[((size_t)(s * 9 + tap) * g.K + k) * g.C + cc] = acc[nt][r];
-            }
-        }
-    }
-}
-
-// ---- backward, pass A, one-hot, bf16 activations --------------------------------------------------------------------
-// Same algorithm as k_sean_bwd_a_onehot, restructured for the bf16 path, where this kernel is the largest single item of
-// a training step (1.9 ms per launch at x4 / B=32 in the version above: a quarter of it the exact-fp32 MFMA phase, the
-// rest a memory phase with one 4-pixel step in flight per wave):
-//  * the segmented sum dD_tap = O_tap^T . G runs on v_mfma_f32_16x16x32_bf16 (K = 32 pixels per instruction instead of 4,
-//    at half the cycles): the one-hot operand is exact in bf16, G is stored in LDS in bf16 (its consumers, the
-//    gamma_s / beta_s kernels' gradients, are sums over ~10^5 pixels) and read with ds_read_b64_tr_b16 (a lane needs
-//    8 consecutive PIXELS of one channel);
-//  * phase 1 keeps all four 4-pixel steps of a tile in flight (unconditional clamped loads into registers), and the next
-//    tile's loads are issued before the matrix phase, so HBM latency hides under it and under the barriers.
+template <typename T> struct SeanBwdCfg;
+template <> struct SeanBwdCfg<bf16_t> { static constexpr int TH = 4, NP = 1; };   // tile rows, bf16 pieces of G
+template <> struct SeanBwdCfg<float>  { static constexpr int TH = 2, NP = 3; };   // three G planes: 2-row tiles (LDS)
 #define SB16_GST 160           // sG pixel stride in bf16 elements (320 B: the 4 pixel rows of a transposed read fall in
                                // four disjoint 64-byte bank ranges)
 // Eight consecutive region bytes starting at an arbitrary (unaligned) LDS address, as two dwords: three aligned
@@ -805,24 +628,34 @@ __device__ __forceinline__ void lds_ld8_unaligned(const unsigned char* p, unsign
 #endif
 }
 
-struct SeanBwdLoads {
-    bf16x4 g0[4], ov[4], tv[4], g2[4], b2[4];
-};
+template <typename T, int NST> struct SeanBwdLoads;
+template <int NST> struct SeanBwdLoads<bf16_t, NST> { bf16x4 g0[NST], ov[NST], tv[NST], g2[NST], b2[NST]; };
+template <int NST> struct SeanBwdLoads<float, NST> { float4 g0[NST], ov[NST], tv[NST], g2[NST], b2[NST]; };
+__device__ __forceinline__ float4 sean_f4(bf16x4 v) {
+    return make_float4(dasr_bf2f(v[0]), dasr_bf2f(v[1]), dasr_bf2f(v[2]), dasr_bf2f(v[3]));
+}
+__device__ __forceinline__ float4 sean_f4(float4 v) { return v; }
+__device__ __forceinline__ void sean_ldraw(const bf16_t* p, bf16x4& v) { v = *(const bf16x4*)p; }
+__device__ __forceinline__ void sean_ldraw(const float* p, float4& v) { v = *(const float4*)p; }
 
-__global__ void __launch_bounds__(512) k_sean_bwd_a_onehot_bf16(
-    SeanGeom g, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const bf16_t* __restrict__ t,
-    const float* __restrict__ mean, const float* __restrict__ var, const bf16_t* __restrict__ gb2,
+template <typename T>
+__global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
+    SeanGeom g, const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ t,
+    const float* __restrict__ mean, const float* __restrict__ var, const T* __restrict__ gb2,
     const unsigned char* __restrict__ region, const int* __restrict__ flag, const float* __restrict__ D,
     const float* __restrict__ bias_g, const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
-    const float* __restrict__ alpha_b, bf16_t* __restrict__ dt, bf16_t* __restrict__ dgb2, float* __restrict__ dD_slabs,
+    const float* __restrict__ alpha_b, T* __restrict__ dt, T* __restrict__ dgb2, float* __restrict__ dD_slabs,
     float* __restrict__ dbias_g, float* __restrict__ dbias_b, float* __restrict__ dalpha_g,
-    float* __restrict__ dalpha_b, bf16_t* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
+    float* __restrict__ dalpha_b, T* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
     if (flag && *flag != 0) return;
     DASR_DYN_SMEM(smem);
+    constexpr int SB_TH = SeanBwdCfg<T>::TH, NP = SeanBwdCfg<T>::NP;
+    constexpr int WPR = 8 / SB_TH, NST = SB_TH;                 // waves per tile row, 4-pixel steps per wave and tile
+    constexpr int PLANE = SB_TH * SF_TW * SB16_GST;             // one bf16 plane of G
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                                   // [18][K+1][64]
-    bf16_t* sG = (bf16_t*)(sD + 18 * K1 * 64);                  // [SB_TH*SF_TW][SB16_GST]: gamma part | beta part
-    float* sred = (float*)(sG + SB_TH * SF_TW * SB16_GST);      // [8 waves][18][16] reduction scratch
+    bf16_t* sG = (bf16_t*)(sD + 18 * K1 * 64);                  // [NP][SB_TH*SF_TW][SB16_GST]: gamma part | beta part
+    float* sred = (float*)(sG + NP * PLANE);                    // [8 waves][18][16] reduction scratch
     unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);   // [(SB_TH+2)*(SF_TW+2)]
     const int b = blockIdx.y, c0 = blockIdx.z * 64;
     const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
@@ -850,25 +683,25 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot_bf16(
         for (int r = 0; r < 4; ++r) acc[q][r] = 0.f;
     sean_stage_D(g, D, sD, b, c0);
     const int mydy = wv / 3, mydx = wv % 3;     // tap of this wave (taps 0..7); tap 8 = (2,2) is shared
-    const int ly = wv >> 1;                     // phase 1: wave w -> tile row w>>1, columns 16*(w&1) .. +15
-    // unconditional loads of the tile's four 4-pixel steps (coordinates clamped into the image)
-    auto issue = [&](int tile, SeanBwdLoads& f) {
+    const int ly = wv / WPR, lxw = (SF_TW / WPR) * (wv % WPR);   // phase 1: this wave's tile row and first column
+    // unconditional loads of the tile's 4-pixel steps (coordinates clamped into the image)
+    auto issue = [&](int tile, SeanBwdLoads<T, NST>& f) {
         const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
         const int y = imin(y0 + ly, g.H - 1);
         const size_t row = ((size_t)b * g.H + y) * g.W;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int x = imin(x0 + 16 * (wv & 1) + 4 * u + ps, g.W - 1);
+        for (int u = 0; u < NST; ++u) {
+            const int x = imin(x0 + lxw + 4 * u + ps, g.W - 1);
             const size_t p = row + x;
-            f.g0[u] = *(const bf16x4*)(dout + p * g.C + c);
-            f.ov[u] = *(const bf16x4*)(out + p * g.C + c);
-            f.tv[u] = *(const bf16x4*)(t + p * g.C + c);
-            f.g2[u] = *(const bf16x4*)(gb2 + p * 2 * g.C + c);
-            f.b2[u] = *(const bf16x4*)(gb2 + p * 2 * g.C + g.C + c);
+            sean_ldraw(dout + p * g.C + c, f.g0[u]);
+            sean_ldraw(out + p * g.C + c, f.ov[u]);
+            sean_ldraw(t + p * g.C + c, f.tv[u]);
+            sean_ldraw(gb2 + p * 2 * g.C + c, f.g2[u]);
+            sean_ldraw(gb2 + p * 2 * g.C + g.C + c, f.b2[u]);
         }
     };
-    auto f4 = [](bf16x4 v) { return make_float4(dasr_bf2f(v[0]), dasr_bf2f(v[1]), dasr_bf2f(v[2]), dasr_bf2f(v[3])); };
-    SeanBwdLoads cur;
+    auto f4 = [](auto v) { return sean_f4(v); };
+    SeanBwdLoads<T, NST> cur;
     if ((int)blockIdx.x < ntiles) issue(blockIdx.x, cur);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
@@ -879,8 +712,8 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot_bf16(
         {
             const int y = y0 + ly;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int lx = 16 * (wv & 1) + 4 * u + ps, x = x0 + lx;
+            for (int u = 0; u < NST; ++u) {
+                const int lx = lxw + 4 * u + ps, x = x0 + lx;
                 float4 G1 = zero4, B1 = zero4;
                 if (live && y < g.H && x < g.W) {
                     const size_t p = ((size_t)b * g.H + y) * g.W + x;
@@ -919,8 +752,17 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot_bf16(
                     S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
                 }
                 bf16_t* gp = sG + (ly * SF_TW + lx) * SB16_GST + 4 * cq;
-                st4(gp, G1);                       // channels 0..63: gamma part
-                st4(gp + 64, B1);                  // channels 64..127: beta part
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {  // bf16 pieces of G: value, then the exact residuals (fp32 activations)
+                    st4(gp + pc * PLANE, G1);      // channels 0..63: gamma part
+                    st4(gp + pc * PLANE + 64, B1); // channels 64..127: beta part
+                    if (pc + 1 < NP) {
+                        G1 = make_float4(G1.x - round_to<bf16_t>(G1.x), G1.y - round_to<bf16_t>(G1.y),
+                                         G1.z - round_to<bf16_t>(G1.z), G1.w - round_to<bf16_t>(G1.w));
+                        B1 = make_float4(B1.x - round_to<bf16_t>(B1.x), B1.y - round_to<bf16_t>(B1.y),
+                                         B1.z - round_to<bf16_t>(B1.z), B1.w - round_to<bf16_t>(B1.w));
+                    }
+                }
                 DASR_SCHED_BARRIER();              // one step's gather rows at a time (256-VGPR budget)
             }
         }
@@ -943,7 +785,10 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot_bf16(
                     a_8[j] = dasr_f2bf((int)((t8_lo >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
                     a_8[4 + j] = dasr_f2bf((int)((t8_hi >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
                 }
-                const bf16_t* gq = sG + (s * SF_TW + 8 * kg + tq) * SB16_GST + 4 * tp;
+                const bf16_t* gq0 = sG + (s * SF_TW + 8 * kg + tq) * SB16_GST + 4 * tp;
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {
+                const bf16_t* gq = gq0 + pc * PLANE;
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
                     const bf16x4 lo = lds_read_tr16(gq + 16 * nt), hi = lds_read_tr16(gq + 16 * nt + 4 * SB16_GST);
@@ -962,6 +807,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot_bf16(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { bv[e] = lo[e]; bv[4 + e] = hi[e]; }
                     acc[8] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_8, bv, acc[8], 0, 0, 0);
+                }
                 }
             }
         }
@@ -1166,21 +1012,13 @@ static int sean_bwd_impl(const T* dout, const T* out, const T* t, const float* m
     }
     if (fast) {
         int nblk = sean_bwd_blocks_per_sample(B, H, W);
-        int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + SB_TH - 1) / SB_TH);
-        size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64 + SB_TH * SF_TW * SB_GST + 8 * 18 * 16) +
-                     (SB_TH + 2) * (SF_TW + 2);
-        if (sizeof(T) == 2) {
-            const size_t lds16 = sizeof(float) * (size_t)(18 * (K + 1) * 64 + 8 * 18 * 16) +
-                                 sizeof(bf16_t) * (size_t)(SB_TH * SF_TW * SB16_GST) + (SB_TH + 2) * (SF_TW + 2) + 8;
-            DASR_LAUNCH(k_sean_bwd_a_onehot_bf16, dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds16, stream, g,
-                        (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)t, mean, var, (const bf16_t*)gb2, region,
-                        onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, (bf16_t*)dt, (bf16_t*)dgb2, slabs, dbias_g, dbias_b,
-                        dalpha_g, dalpha_b, (bf16_t*)dres, S, relu, eps, ntiles);
-        } else {
-            DASR_LAUNCH((k_sean_bwd_a_onehot<T>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
-                        mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
-                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
-        }
+        constexpr int TH = SeanBwdCfg<T>::TH, NP = SeanBwdCfg<T>::NP;
+        int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + TH - 1) / TH);
+        size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64 + 8 * 18 * 16) +
+                     sizeof(bf16_t) * (size_t)(NP * TH * SF_TW * SB16_GST) + (TH + 2) * (SF_TW + 2) + 8;
+        DASR_LAUNCH((k_sean_bwd_a_onehot<T>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
+                    mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
+                    dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
         size_t n = (size_t)B * 18 * K * C;
         DASR_LAUNCH(k_sean_dD_reduce, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, (const float*)slabs, onehot_flag, dD,
                     18 * K * C, nblk, n);
