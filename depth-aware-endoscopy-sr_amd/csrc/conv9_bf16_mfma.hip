@@ -1,0 +1,364 @@
+// conv9_bf16_mfma.hip — the generator's 9x9 output convolution (conv_output, sftmd_arch.py:910,948: 32 -> 3 channels at
+// HR resolution) on the bf16 matrix cores, for the mixed-precision path: bf16 activations x (32 channels), fp32 kernel,
+// fp32 3-channel image side (y, dy).  Same folding as conv9_mfma.hip - one kernel axis goes into N so that an MFMA tile is
+// 27/32 full - with v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_32x32x2_f32 (16x the rate; at x4 / B=32 the fp32
+// version of these three kernels was 22 ms of a 230 ms step):
+//   forward:  P[q][(kw,co)] = sum_{kh,ci} x[q.y+kh-4, q.x][ci] * w[kh][kw][ci][co]        M = pixels q, N = 27, K = 9*32
+//             y[p][co]      = sum_kw P[(p.y, p.x+kw-4)][(kw,co)]                            (9-term shift-add via LDS, fp32)
+//   dgrad:    dx[q][ci]     = sum_kh sum_k' E[q.y-kh+4][q.x][k'] * Wd[kh][k'][ci]            M = pixels, N = 32 ci, K = 9*32
+//   wgrad:    dW[kh][k'][ci] = sum_q x[q][ci] * E[q.y-kh+4][q.x][k']                         M = ci, N = 27, K = pixels
+// with k' = 3*(8-kw) + co and E[row][px][k'] = the 27 consecutive values of the 3-channel dy row starting at pixel px-4
+// (zero for k' >= 27): the dy tile is staged once (fp32), then expanded into this aligned bf16 image so that an MFMA
+// operand is one 16-byte LDS read (dgrad) or two transposed reads (wgrad).  The weight and bias gradients and y stay fp32;
+// dy is rounded to bf16 as an MFMA operand (dx is a bf16 tensor anyway; dW sums ~10^6 such products).
+#include "bf16.h"
+#include "conv_kernels.h"
+
+#define Q_TH 8            // tile rows
+#define Q_TQ 64           // tile columns
+#define Q_PST 28          // P row stride in floats (27 used)
+#define Q_DYW ((Q_TQ + 8) * 3 + 8)   // fp32 dy tile row stride: 72 px * 3 ch + pad
+
+typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
+
+struct Conv9BfArgs {
+    const bf16_t* x;     // fwd/wgrad: [B,H,W,Cin]
+    const float* w;      // HWIO [9][9][Cin][Cout] (fp32)
+    const float* bias;   // fwd
+    const float* dy;     // dgrad/wgrad: [B,H,W,Cout] (fp32)
+    void* out;           // fwd: y (float); dgrad: dx (bf16_t); wgrad: slabs (float)
+    int B, H, W, Cin, Cout;
+    int accumulate, P, ntiles;
+};
+
+// ------------------------------------------------------------------------------------------ forward
+// 512 threads: wave w owns tile row w (two 32-pixel M-tiles).  Input tile 16 rows x 64 columns x 32 channels.
+__global__ void __launch_bounds__(512) k_conv9x9_fwd_bf16(Conv9BfArgs a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int CKP = 40;                                        // 80-byte pixel stride: conflict-free ds_read_b128
+    bf16_t* sIn = (bf16_t*)smem;                                   // [16][64][CKP]   (later: P [8][64][PST] fp32)
+    bf16_t* sW = sIn + (Q_TH + 8) * Q_TQ * CKP;                    // [9 kh][32 n][CKP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int TWO = Q_TQ - 8;
+    const int tiles_x = (a.W + TWO - 1) / TWO;
+    const int x0 = (blockIdx.x % tiles_x) * TWO, y0 = (blockIdx.x / tiles_x) * Q_TH, b = blockIdx.y;
+    const int NN = 9 * a.Cout;   // <= 27
+    const BufRsrc rx = dasr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.Cin, (size_t)a.H * a.W * a.Cin * sizeof(bf16_t));
+    constexpr int NPC = (Q_TH + 8) * Q_TQ * 4 / 512;               // 8 pieces of 16 bytes per thread
+    unsigned offx[NPC];
+#pragma unroll
+    for (int u = 0; u < NPC; ++u) {
+        const int idx = tid + 512 * u, pix = idx >> 2, q4 = idx & 3;
+        const int gy = y0 - 4 + pix / Q_TQ, gx = x0 - 4 + pix % Q_TQ;
+        offx[u] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                      ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * q4) * (int)sizeof(bf16_t)) : DASR_OOB;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int c0 = 0; c0 < a.Cin; c0 += 32) {
+        q_u32x4 vin[NPC];
+#pragma unroll
+        for (int u = 0; u < NPC; ++u) vin[u] = dasr_buffer_load16(rx, offx[u] + (unsigned)c0 * (unsigned)sizeof(bf16_t));
+        __syncthreads();                                   // every wave is done with the previous chunk
+#pragma unroll
+        for (int u = 0; u < NPC; ++u) {
+            const int idx = tid + 512 * u;
+            *(q_u32x4*)(sIn + (idx >> 2) * CKP + 8 * (idx & 3)) = vin[u];
+        }
+        // kernel slice: sW[kh][n = kw*Cout+co][ci] (zero rows for n >= 9*Cout); all 18 loads of a thread first
+        {
+            float wq[18];
+#pragma unroll
+            for (int u = 0; u < 18; ++u) {
+                const int e = tid + 512 * u, ci = e & 31, n = (e >> 5) & 31, kh = e >> 10;
+                const int nn = n < NN ? n : 0, kw = nn / a.Cout, co = nn % a.Cout;
+                const float v = a.w[(((size_t)kh * 9 + kw) * a.Cin + c0 + ci) * a.Cout + co];
+                wq[u] = n < NN ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 18; ++u) {
+                const int e = tid + 512 * u, ci = e & 31, n = (e >> 5) & 31, kh = e >> 10;
+                sW[(kh * 32 + n) * CKP + ci] = dasr_f2bf(wq[u]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kh = 0; kh < 9; ++kh)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bf16x8 Bf = *(const bf16x8*)(sW + (kh * 32 + li) * CKP + 16 * q + 8 * lh);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const bf16x8 A = *(const bf16x8*)(sIn + ((wv + kh) * Q_TQ + 32 * m + li) * CKP + 16 * q + 8 * lh);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[m], 0, 0, 0);
+                }
+            }
+    }
+    __syncthreads();
+    float* sP = (float*)smem;   // [8][64][PST]
+    if (li < Q_PST) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int qx = 32 * m + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                sP[(wv * Q_TQ + qx) * Q_PST + li] = acc[m][g];
+            }
+    }
+    __syncthreads();
+    const int nout = Q_TH * TWO * a.Cout;
+    float* y = (float*)a.out;
+    for (int idx = tid; idx < nout; idx += 512) {
+        const int co = idx % a.Cout, ox = (idx / a.Cout) % TWO, r = idx / (a.Cout * TWO);
+        const int gy = y0 + r, gx = x0 + ox;
+        if (gy >= a.H || gx >= a.W) continue;
+        float v = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int kw = 0; kw < 9; ++kw) v += sP[(r * Q_TQ + ox + kw) * Q_PST + kw * a.Cout + co];
+        y[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ the E image
+// sDy: fp32 dy tile, rows y0-4 .. y0+11, columns x0-4 .. x0+67, Cout channels interleaved (zero outside the image).
+// E[row][px][k'] (bf16, EST elements per pixel) = sDy[row][Cout*px + k'] for k' < 9*Cout, else 0.
+template <int NTHR>
+__device__ __forceinline__ void q_stage_dy(const Conv9BfArgs& a, float* sDy, int b, int y0, int x0, int tid) {
+    const int rowf = (Q_TQ + 8) * a.Cout;
+    constexpr int N = (Q_TH + 8) * Q_DYW, NI = (N + NTHR - 1) / NTHR;
+    float v[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int idx = tid + NTHR * u;
+        const int f = idx % Q_DYW, ry = idx / Q_DYW;
+        v[u] = 0.f;
+        if (idx < N && f < rowf) {
+            const int gy = y0 - 4 + ry, gx = x0 - 4 + f / a.Cout, co = f % a.Cout;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v[u] = a.dy[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int idx = tid + NTHR * u;
+        if (idx < N) sDy[idx] = v[u];
+    }
+}
+template <int NTHR, int EST>
+__device__ __forceinline__ void q_build_E(const Conv9BfArgs& a, const float* sDy, bf16_t* sE, int tid) {
+    const int KK = 9 * a.Cout;
+    for (int pc = tid; pc < (Q_TH + 8) * Q_TQ * 4; pc += NTHR) {          // 16-byte pieces: (row, px, 8 k')
+        const int p8 = pc & 3, px = (pc >> 2) % Q_TQ, row = pc / (4 * Q_TQ);
+        const float* src = sDy + row * Q_DYW + a.Cout * px + 8 * p8;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = dasr_f2bf(8 * p8 + j < KK ? src[j] : 0.f);
+        *(bf16x8*)(sE + (row * Q_TQ + px) * EST + 8 * p8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dgrad
+// tile: 8 rows x 64 columns of dx pixels x 32 input channels (blockIdx.z selects the 32-channel slice); 512 threads,
+// wave w owns tile row w
+__global__ void __launch_bounds__(512) k_conv9x9_dgrad_bf16(Conv9BfArgs a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int EST = 40;                                        // 80-byte pixel stride (conflict-free ds_read_b128)
+    bf16_t* sE = (bf16_t*)smem;                                    // [16][64][EST]
+    bf16_t* sW = sE + (Q_TH + 8) * Q_TQ * EST;                     // [9 kh][32 ci][EST]: Wd[kh][k'][ci], k' contiguous
+    float* sDy = (float*)(sW + 9 * 32 * EST);                      // [16][DYW]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (a.W + Q_TQ - 1) / Q_TQ;
+    const int x0 = (blockIdx.x % tiles_x) * Q_TQ, y0 = (blockIdx.x / tiles_x) * Q_TH, b = blockIdx.y;
+    const int n0 = blockIdx.z * 32;
+    const int KK = 9 * a.Cout;
+    q_stage_dy<512>(a, sDy, b, y0, x0, tid);
+    {                                                              // Wd[kh][k'][ci] = w[kh][8 - k'/Cout][ci][k' % Cout]
+        float wq[18];
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {
+            const int e = tid + 512 * u, kp = e & 31, ci = (e >> 5) & 31, kh = e >> 10;
+            const int kk = kp < KK ? kp : 0, kw = 8 - kk / a.Cout, co = kk % a.Cout;
+            const float v = a.w[(((size_t)kh * 9 + kw) * a.Cin + n0 + ci) * a.Cout + co];
+            wq[u] = kp < KK ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {
+            const int e = tid + 512 * u, kp = e & 31, ci = (e >> 5) & 31, kh = e >> 10;
+            sW[(kh * 32 + ci) * EST + kp] = dasr_f2bf(wq[u]);
+        }
+    }
+    __syncthreads();
+    q_build_E<512, EST>(a, sDy, sE, tid);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 9; ++kh)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bf16x8 Bf = *(const bf16x8*)(sW + (kh * 32 + li) * EST + 16 * q + 8 * lh);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                // dy row of output row wv for this kh: wv - kh + 4 (+4 for the tile's first row y0-4) = wv - kh + 8
+                const bf16x8 A = *(const bf16x8*)(sE + ((wv - kh + 8) * Q_TQ + 32 * m + li) * EST + 16 * q + 8 * lh);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[m], 0, 0, 0);
+            }
+        }
+    bf16_t* dx = (bf16_t*)a.out;
+    const int gy = y0 + wv;
+    if (gy < a.H) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int gx = x0 + 32 * m + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (gx >= a.W) continue;
+                const size_t o = (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + n0 + li;
+                float v = acc[m][g];
+                if (a.accumulate) v += dasr_bf2f(dx[o]);
+                dx[o] = dasr_f2bf(v);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// Workgroup (512 threads) walks a strip of 8 x 64 pixel tiles; wave w owns tile row w and keeps nine [32 ci x 32 k']
+// accumulators (one per kh).  Operands through transposed LDS reads: A = x^T (8 consecutive pixels of one channel),
+// B = E^T.  Each wave writes its own slab [9][32][32]; k_conv9_wgrad_reduce_bf16 sums the slabs and un-folds k'.
+__global__ void __launch_bounds__(512) k_conv9x9_wgrad_bf16(Conv9BfArgs a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int EST = 32;                                        // 64-byte pixel stride: conflict-free transposed reads
+    bf16_t* sX = (bf16_t*)smem;                                    // [8][64][32]
+    bf16_t* sE = sX + Q_TH * Q_TQ * 32;                            // [16][64][EST]
+    float* sDy = (float*)(sE + (Q_TH + 8) * Q_TQ * EST);           // [16][DYW]
+    const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6)), li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (a.W + Q_TQ - 1) / Q_TQ, tiles_y = (a.H + Q_TH - 1) / Q_TH;
+    const int ci0 = blockIdx.x * 32;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx * Q_TQ, y0 = ty * Q_TH;
+        const BufRsrc rx = dasr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.Cin, (size_t)a.H * a.W * a.Cin * sizeof(bf16_t));
+        constexpr int NXP = Q_TH * Q_TQ * 4 / 512;                 // 4 pieces per thread
+        q_u32x4 vx[NXP];
+#pragma unroll
+        for (int u = 0; u < NXP; ++u) {
+            const int idx = tid + 512 * u, pix = idx >> 2, q4 = idx & 3;
+            const int gy = y0 + pix / Q_TQ, gx = x0 + pix % Q_TQ;
+            vx[u] = dasr_buffer_load16(rx, (gy < a.H && gx < a.W)
+                                               ? (unsigned)(((gy * a.W + gx) * a.Cin + ci0 + 8 * q4) * (int)sizeof(bf16_t))
+                                               : DASR_OOB);
+        }
+        __syncthreads();                         // every wave is done with the previous tile
+        q_stage_dy<512>(a, sDy, b, y0, x0, tid);
+#pragma unroll
+        for (int u = 0; u < NXP; ++u) {
+            const int idx = tid + 512 * u;
+            *(q_u32x4*)(sX + (idx >> 2) * 32 + 8 * (idx & 3)) = vx[u];
+        }
+        __syncthreads();
+        q_build_E<512, EST>(a, sDy, sE, tid);
+        __syncthreads();
+        // K-step = 16 consecutive pixels of this wave's row
+#pragma unroll 2
+        for (int s = 0; s < Q_TQ / 16; ++s) {
+            const int px = 16 * s + 8 * lh + tq;
+            const bf16_t* xp = sX + (wv * Q_TQ + px) * 32 + 16 * tg + 4 * tp;
+            const bf16x4 a0 = lds_read_tr16(xp), a1 = lds_read_tr16(xp + 4 * 32);
+            bf16x8 av;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { av[e] = a0[e]; av[4 + e] = a1[e]; }
+#pragma unroll
+            for (int kh = 0; kh < 9; ++kh) {
+                const bf16_t* ep = sE + ((wv - kh + 8) * Q_TQ + px) * EST + 16 * tg + 4 * tp;
+                const bf16x4 b0 = lds_read_tr16(ep), b1 = lds_read_tr16(ep + 4 * EST);
+                bf16x8 bv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[kh], 0, 0, 0);
+            }
+        }
+    }
+    float* slab = (float*)a.out + ((size_t)(blockIdx.y * 8 + wv) * gridDim.x + blockIdx.x) * (9 * 32 * 32);
+#pragma unroll
+    for (int kh = 0; kh < 9; ++kh)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int ci = (g & 3) + 8 * (g >> 2) + 4 * lh;
+            slab[(kh * 32 + ci) * 32 + li] = acc[kh][g];
+        }
+}
+
+// dw[kh][kw][ci][co] = sum over slabs of slab[cig][kh][ci%32][(8-kw)*Cout+co]; the slab range is split over
+// blockIdx.y (partial sums meet in the zeroed dw through float atomics)
+__global__ void __launch_bounds__(256) k_conv9_wgrad_reduce_bf16(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                 int Cin, int Cout, int nslabs, int cgroups, int per_y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 81 * Cin * Cout;
+    if (i >= n) return;
+    const int co = i % Cout, ci = (i / Cout) % Cin, kw = (i / (Cout * Cin)) % 9, kh = i / (Cout * Cin * 9);
+    const int np = (8 - kw) * Cout + co;
+    const float* p = slabs + (size_t)(ci / 32) * (9 * 32 * 32) + (kh * 32 + (ci & 31)) * 32 + np;
+    const int s0 = blockIdx.y * per_y;
+    const int s1 = s0 + per_y < nslabs ? s0 + per_y : nslabs;
+    float acc = 0.f;
+    for (int s = s0; s < s1; ++s) acc += p[(size_t)s * cgroups * (9 * 32 * 32)];
+    atomicAdd(&dw[i], acc);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+// (conv9_mfma_supported(g) decides; these are reached from the *_bf16 entry points of conv_api.hip)
+int conv9_bf16_fwd(const ConvGeom& g, const bf16_t* x, const float* w, const float* bias, float* y, void* stream) {
+    Conv9BfArgs a{x, w, bias, nullptr, y, g.B, g.H, g.W, g.Cin, g.Cout, 0, 0, 0};
+    const int TWO = Q_TQ - 8;
+    const int tiles = ((g.W + TWO - 1) / TWO) * ((g.H + Q_TH - 1) / Q_TH);
+    size_t lds = sizeof(bf16_t) * (size_t)((Q_TH + 8) * Q_TQ * 40 + 9 * 32 * 40);
+    const size_t ldsP = sizeof(float) * (size_t)(Q_TH * Q_TQ * Q_PST);
+    if (ldsP > lds) lds = ldsP;
+    DASR_LAUNCH(k_conv9x9_fwd_bf16, dim3(tiles, g.B), dim3(512), lds, stream, a);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+int conv9_bf16_dgrad(const ConvGeom& g, const float* dconv, const float* w, bf16_t* dx, int accumulate, void* stream) {
+    Conv9BfArgs a{nullptr, w, nullptr, dconv, dx, g.B, g.H, g.W, g.Cin, g.Cout, accumulate, 0, 0};
+    const int tiles = ((g.W + Q_TQ - 1) / Q_TQ) * ((g.H + Q_TH - 1) / Q_TH);
+    const size_t lds = sizeof(bf16_t) * (size_t)((Q_TH + 8) * Q_TQ * 40 + 9 * 32 * 40) + sizeof(float) * (size_t)((Q_TH + 8) * Q_DYW);
+    DASR_LAUNCH(k_conv9x9_dgrad_bf16, dim3(tiles, g.B, g.Cin / 32), dim3(512), lds, stream, a);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+static void conv9_bf16_wgrad_plan(const ConvGeom& g, int& ntiles, int& P) {
+    ntiles = g.B * ((g.H + Q_TH - 1) / Q_TH) * ((g.W + Q_TQ - 1) / Q_TQ);
+    P = 256 / (g.Cin / 32);
+    if (P > ntiles) P = ntiles;
+    if (P < 1) P = 1;
+}
+size_t conv9_bf16_wgrad_workspace(const ConvGeom& g) {
+    int ntiles, P;
+    conv9_bf16_wgrad_plan(g, ntiles, P);
+    return sizeof(float) * (size_t)P * 8 * (g.Cin / 32) * 9 * 32 * 32;
+}
+int conv9_bf16_wgrad(const ConvGeom& g, const bf16_t* x, const float* dconv, float* dw, void* workspace, void* stream) {
+    int ntiles, P;
+    conv9_bf16_wgrad_plan(g, ntiles, P);
+    Conv9BfArgs a{x, nullptr, nullptr, dconv, workspace, g.B, g.H, g.W, g.Cin, g.Cout, 0, P, ntiles};
+    const size_t lds = sizeof(bf16_t) * (size_t)(Q_TH * Q_TQ * 32 + (Q_TH + 8) * Q_TQ * 32) +
+                       sizeof(float) * (size_t)((Q_TH + 8) * Q_DYW);
+    DASR_LAUNCH(k_conv9x9_wgrad_bf16, dim3(g.Cin / 32, P), dim3(512), lds, stream, a);
+    const int n = 81 * g.Cin * g.Cout;
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * n, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    const int nslabs = P * 8, ysplit = nslabs >= 64 ? 32 : 1;
+    DASR_LAUNCH(k_conv9_wgrad_reduce_bf16, dim3(dasr_cdiv(n, 256), ysplit), dim3(256), 0, stream, (const float*)workspace, dw,
+                g.Cin, g.Cout, nslabs, g.Cin / 32, (nslabs + ysplit - 1) / ysplit);
+    DASR_RETURN_LAUNCH_STATUS();
+}

@@ -344,9 +344,6 @@ static int conv9_fwd_impl(const ConvGeom& g, const TX* x, const float* w, const 
 int conv9_mfma_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* stream) {
     return conv9_fwd_impl<float>(g, x, w, bias, y, stream);
 }
-int conv9_mfma_fwd_bf16(const ConvGeom& g, const bf16_t* x, const float* w, const float* bias, float* y, void* stream) {
-    return conv9_fwd_impl<bf16_t>(g, x, w, bias, y, stream);
-}
 template <typename TX>
 static int conv9_dgrad_impl(const ConvGeom& g, const float* dconv, const float* w, TX* dx, int accumulate,
                             const TX* mask_src, int mask_act, int unps_r, void* stream) {
@@ -364,9 +361,6 @@ static int conv9_dgrad_impl(const ConvGeom& g, const float* dconv, const float* 
 int conv9_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate,
                      const float* mask_src, int mask_act, int unps_r, void* stream) {
     return conv9_dgrad_impl<float>(g, dconv, w, dx, accumulate, mask_src, mask_act, unps_r, stream);
-}
-int conv9_mfma_dgrad_bf16(const ConvGeom& g, const float* dconv, const float* w, bf16_t* dx, int accumulate, void* stream) {
-    return conv9_dgrad_impl<bf16_t>(g, dconv, w, dx, accumulate, nullptr, 0, 1, stream);
 }
 static void conv9_wgrad_plan(const ConvGeom& g, int& ntiles, int& P) {
     ntiles = g.B * ((g.H + C9_TH - 1) / C9_TH) * ((g.W + C9_TQ - 1) / C9_TQ);
@@ -396,7 +390,4 @@ static int conv9_wgrad_impl(const ConvGeom& g, const TX* x, const float* dconv, 
 }
 int conv9_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream) {
     return conv9_wgrad_impl<float>(g, x, dconv, dw, workspace, stream);
-}
-int conv9_mfma_wgrad_bf16(const ConvGeom& g, const bf16_t* x, const float* dconv, float* dw, void* workspace, void* stream) {
-    return conv9_wgrad_impl<bf16_t>(g, x, dconv, dw, workspace, stream);
 }

@@ -193,7 +193,7 @@ extern "C" int dasr_conv2d_fwd_bf16(const void* x, const void* w, const float* b
             return conv_c1_fwd_bf16(g, (const float*)x, (const float*)w, bias, (bf16_t*)y, act, stream);
         case 3:
             if (ps_r != 1 || residual || act != DASR_ACT_NONE) return DASR_E_UNSUPPORTED;
-            return conv9_mfma_fwd_bf16(g, (const bf16_t*)x, (const float*)w, bias, (float*)y, stream);
+            return conv9_bf16_fwd(g, (const bf16_t*)x, (const float*)w, bias, (float*)y, stream);
     }
     return DASR_E_UNSUPPORTED;
 }
@@ -218,7 +218,7 @@ extern "C" int dasr_conv2d_dgrad_bf16(const void* dconv, const void* w, unsigned
     if (conv_bf16_dgrad_supported(g))
         return conv_bf16_dgrad(g, (const bf16_t*)dconv, (const bf16_t*)w, (bf16_t*)dx, accumulate, stream);
     if (conv9_mfma_supported(g))
-        return conv9_mfma_dgrad_bf16(g, (const float*)dconv, (const float*)w, (bf16_t*)dx, accumulate, stream);
+        return conv9_bf16_dgrad(g, (const float*)dconv, (const float*)w, (bf16_t*)dx, accumulate, stream);
     return DASR_E_UNSUPPORTED;
 }
 extern "C" size_t dasr_conv2d_wgrad_workspace_bf16(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
@@ -226,7 +226,7 @@ extern "C" size_t dasr_conv2d_wgrad_workspace_bf16(int B, int H, int W, int Cin,
     ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
     if (check_geom(g) != DASR_OK) return 0;
     if (conv_bf16_wgrad_supported(g)) return conv_bf16_wgrad_workspace(g);
-    if (conv9_mfma_supported(g)) return conv9_mfma_wgrad_workspace(g);
+    if (conv9_mfma_supported(g)) return conv9_bf16_wgrad_workspace(g);
     return 0;
 }
 // trunk: x bf16, dconv bf16;  output conv: x bf16, dconv f32.  dw (plain HWIO) and dbias are fp32.
@@ -242,8 +242,8 @@ extern "C" int dasr_conv2d_wgrad_bf16(const unsigned short* x, const void* dconv
         return conv_bf16_wgrad(g, (const bf16_t*)x, (const bf16_t*)dconv, dw, dbias, workspace, stream);
     }
     if (conv9_mfma_supported(g)) {
-        if (workspace_bytes < conv9_mfma_wgrad_workspace(g)) return DASR_E_WORKSPACE;
-        rc = conv9_mfma_wgrad_bf16(g, (const bf16_t*)x, (const float*)dconv, dw, workspace, stream);
+        if (workspace_bytes < conv9_bf16_wgrad_workspace(g)) return DASR_E_WORKSPACE;
+        rc = conv9_bf16_wgrad(g, (const bf16_t*)x, (const float*)dconv, dw, workspace, stream);
         if (rc) return rc;
         if (dbias) rc = conv_colsum((const float*)dconv, dbias, (size_t)B * Ho * Wo, Cout, stream);
         return rc;

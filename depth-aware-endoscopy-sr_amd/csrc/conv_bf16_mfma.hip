@@ -23,6 +23,7 @@
 // gfx950's transposing LDS read (cdna_hip_programming.md T10): two of them per operand.  Pixel strides of 64 or 192
 // bytes make those reads conflict-free.  Accumulators stay resident over a strip of tiles; slabs + the fixed-order
 // reduction of conv_mfma.hip (k_wgrad_reduce) finish the sum in fp32.
+#include <cstdlib>
 #include "bf16.h"
 #include "conv_kernels.h"
 
@@ -248,7 +249,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
         }
         return;
     }
-    // generic path (ragged last tile column, PixelShuffle(3), PixelShuffle with residual): element by element
+    // generic path (ragged last tile column, PixelShuffle(3), PixelShuffle with residual): element by element.  The
+    // 4-rows-per-wave variant is only launched where the fast path applies (launch_conv_bf16): compiling this path for
+    // it makes the compiler index its 128 accumulators dynamically (they go to scratch).
+    if (CB_MTW > 2) return;
 #pragma unroll
     for (int m = 0; m < CB_MTW; ++m) {
         const int gy = y0 + CB_MTW * wv + m;
@@ -293,21 +297,26 @@ bool conv_bf16_dgrad_supported(const ConvGeom& g) {
            (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
 }
 
-// Tile variants measured on the MI355X at the x4 / B=32 shapes (tools/bench_ops_bf16.py, profiles/r02_conv_bf16_variants.txt):
-// 8-row tiles with two 256-thread workgroups per CU (NW = 4) beat one 512-thread workgroup with 16-row tiles (NW = 8) on
-// every shape but one (the two co-resident workgroups are out of step, so one's barriers and staging overlap the other's
-// MFMAs); four rows per wave (128 accumulators, 16-channel chunks) spills its epilogue and lost 2-3x.  So: NW = 4,
-// two rows per wave, 32-channel chunks.
+// Tile variants (tools/bench_ops_bf16.py, profiles/r02_conv_bf16_variants.txt).  DASR_CB_MTW=4 is an experiment knob of the
+// benchmark tool only.
 template <int WMODE>
 static int launch_conv_bf16(ConvBf16Args& a, void* stream) {
     const int NT = (a.Cout % 64) == 0 ? 2 : 1;
-    const int TH = 8;
+    int MTW = 2;
+#if DASR_DEVICE_BUILD
+    if (const char* e = getenv("DASR_CB_MTW"))
+        if (atoi(e) == 4 && NT == 2 && (a.W % CB_TW) == 0 && (a.H % 32) == 0 &&
+            (a.ps_r == 1 || (a.ps_r == 2 && !a.residual && !a.accumulate)))
+            MTW = 4;
+#endif
+    const int NW = MTW == 4 ? 8 : 4, TH = MTW * NW, CK = MTW == 4 ? 16 : 32;
     const int tiles = ((a.W + CB_TW - 1) / CB_TW) * ((a.H + TH - 1) / TH);
     const int G8 = (tiles * a.B + 7) / 8 * 8;                 // pixel tiles, padded to whole rounds over the 8 XCDs
     const dim3 grid(G8 * (a.Cout / (32 * NT)));
-    const size_t lds = conv_bf16_lds(NT, 4, 2, 32);
-    if (NT == 2) DASR_LAUNCH((k_conv3x3_bf16<2, WMODE, 4, 2, 32>), grid, dim3(256), lds, stream, a);
-    else         DASR_LAUNCH((k_conv3x3_bf16<1, WMODE, 4, 2, 32>), grid, dim3(256), lds, stream, a);
+    const size_t lds = conv_bf16_lds(NT, NW, MTW, CK);
+    if (MTW == 4)     DASR_LAUNCH((k_conv3x3_bf16<2, WMODE, 8, 4, 16>), grid, dim3(512), lds, stream, a);
+    else if (NT == 2) DASR_LAUNCH((k_conv3x3_bf16<2, WMODE, 4, 2, 32>), grid, dim3(256), lds, stream, a);
+    else              DASR_LAUNCH((k_conv3x3_bf16<1, WMODE, 4, 2, 32>), grid, dim3(256), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
 }
 

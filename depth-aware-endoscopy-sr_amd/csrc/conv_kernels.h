@@ -85,6 +85,8 @@ int conv_epilogue_bwd_bf16(const ConvGeom& g, const bf16_t* dy, const bf16_t* y,
 int conv_c1_fwd_bf16(const ConvGeom& g, const float* x, const float* w, const float* bias, bf16_t* y, int act, void* stream);
 int conv_c1_wgrad_bf16(const ConvGeom& g, const float* x, const bf16_t* dy, const bf16_t* yact, int act, float* dw,
                        float* dbias, void* stream);
-int conv9_mfma_fwd_bf16(const ConvGeom& g, const bf16_t* x, const float* w, const float* bias, float* y, void* stream);
-int conv9_mfma_dgrad_bf16(const ConvGeom& g, const float* dconv, const float* w, bf16_t* dx, int accumulate, void* stream);
-int conv9_mfma_wgrad_bf16(const ConvGeom& g, const bf16_t* x, const float* dconv, float* dw, void* workspace, void* stream);
+// conv9_bf16_mfma.hip (the 9x9 output convolution on the bf16 matrix cores: bf16 x / dx, fp32 w / y / dy / dw)
+int conv9_bf16_fwd(const ConvGeom& g, const bf16_t* x, const float* w, const float* bias, float* y, void* stream);
+int conv9_bf16_dgrad(const ConvGeom& g, const float* dconv, const float* w, bf16_t* dx, int accumulate, void* stream);
+size_t conv9_bf16_wgrad_workspace(const ConvGeom& g);
+int conv9_bf16_wgrad(const ConvGeom& g, const bf16_t* x, const float* dconv, float* dw, void* workspace, void* stream);

@@ -949,9 +949,9 @@ def check_replica_protocol(device):
     """An nn.DataParallel replica exposes no parameters (torch >= 1.5): DepthNet must find its weights through the
     module tree's attributes.  A replica built the way replicate() builds one gives the bare net's output bit for
     bit, and its gradients flow back to the original parameters."""
-    case = dict(name="dp", scale=8, which=[0, 1], L=16, nb=4, B=2, H=6, W=8)
+    case = dict(name="dp", scale=2, which=[0, 1], L=16, nb=4, B=2, H=8, W=12)
     net, cfg = build_net(case, device)
-    lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, 2, 6, 8, 8)]
+    lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, 2, 8, 12, 2)]
     sr = net(lq, dm, mk)
     wgt = torch.cos(torch.arange(sr.numel(), dtype=torch.float32) * 0.013).reshape(sr.shape).to(device)
     (sr * wgt).sum().backward()
@@ -1298,20 +1298,36 @@ def check_bf16_ops_vs_fp32_kernels(device, seed=1):
     w32 = ops.conv2d_wgrad_act(depth, dev(dy), a16.float(), (3, 3, 1, Co), ops.ACT_RELU)
     w16 = ops.conv2d_wgrad_act(depth, h(dy), a16, (3, 3, 1, Co), ops.ACT_RELU)
     assert rel_max(w16[0], w32[0]) <= 1e-5 and rel_max(w16[1], w32[1]) <= 1e-5
-    # ---- 9x9 output convolution: bf16 input, fp32 kernel and output
-    B9, H9, W9 = 1, 11, 70
-    x9 = _bf(rn(B9, H9, W9, 32))
-    w9 = ops.pack_hwio(dev(rn(9, 9, 32, 3) * 0.02))
-    b9 = dev(rn(3))
-    y32, y16 = ops.conv2d_fwd(dev(x9), w9, b9, pad=4), ops.conv2d_fwd(h(x9), w9, b9, pad=4)
-    assert y16.dtype == torch.float32 and torch.equal(y16, y32)
-    dy9 = dev(rn(B9, H9, W9, 3))
-    dx32 = ops.conv2d_dgrad(dy9, w9, x9.shape, pad=4)
-    dx16 = ops.conv2d_dgrad(dy9, w9, x9.shape, pad=4, out_dtype=BF16)
-    assert dx16.dtype == BF16 and torch.equal(dx16, dx32.to(BF16))
-    dw32, db32 = ops.conv2d_wgrad(dev(x9), dy9, (9, 9, 32, 3), pad=4)
-    dw16, db16 = ops.conv2d_wgrad(h(x9), dy9, (9, 9, 32, 3), pad=4)
-    assert rel_max(dw16, dw32) <= 1e-5 and rel_max(db16, db32) <= 1e-5
+    # ---- 9x9 output convolution on the bf16 matrix cores: bf16 x, the fp32 kernel and dy rounded to bf16 as MFMA
+    # operands, fp32 accumulation, fp32 y / dw / db.  Reference: torch's fp32 convolution of the SAME rounded operands, so
+    # only the accumulation order differs (and the final rounding of the bf16 dx); ragged tile rows / columns, two batches
+    for (B9, H9, W9) in ((1, 11, 70), (2, 19, 60)):
+        x9 = _bf(rn(B9, H9, W9, 32))
+        w9f = rn(9, 9, 32, 3) * 0.02
+        w9 = ops.pack_hwio(dev(w9f))
+        b9 = rn(3)
+        xt = nchw(x9).clone().requires_grad_(True)
+        wt = _bf(w9f).permute(3, 2, 0, 1).contiguous().requires_grad_(True)          # OIHW of the rounded kernel
+        ref = F.conv2d(xt, wt, b9, padding=4)
+        y16 = ops.conv2d_fwd(h(x9), w9, dev(b9), pad=4)
+        assert y16.dtype == torch.float32 and tuple(y16.shape) == (B9, H9, W9, 3)
+        e = rel_max(nchw(y16), ref.detach())
+        assert e <= 2e-6, ("conv9 bf16 fwd", e)
+        dy9 = rn(B9, H9, W9, 3)
+        gx, gw = torch.autograd.grad(F.conv2d(xt, wt, None, padding=4), (xt, wt), nchw(_bf(dy9)))
+        dx16 = ops.conv2d_dgrad(dev(dy9), w9, x9.shape, pad=4, out_dtype=BF16)
+        e1 = (nchw(dx16.float().cpu()) - gx).abs().max().item() / gx.abs().max().item()
+        assert dx16.dtype == BF16 and e1 <= 2.0 ** -8, ("conv9 bf16 dgrad", e1)
+        acc = h(x9).clone()
+        ops.conv2d_dgrad(dev(dy9), w9, x9.shape, pad=4, out=acc)
+        want = nhwc(gx) + x9
+        e2 = (acc.float().cpu() - want).abs().max().item() / want.abs().max().item()
+        assert e2 <= 2.0 ** -7, ("conv9 bf16 dgrad accumulate", e2)
+        dw16, db16 = ops.conv2d_wgrad(h(x9), dev(dy9), (9, 9, 32, 3), pad=4)
+        e3 = rel_max(dw16.permute(3, 2, 0, 1), gw)
+        e4 = rel_max(db16, dy9.sum((0, 1, 2)))                  # the bias gradient sums the fp32 dy
+        assert e3 <= 1e-5 and e4 <= 1e-5, ("conv9 bf16 wgrad", e3, e4)
+        out["conv9_%dx%d" % (H9, W9)] = (e, e1, e2, e3)
     # ---- epilogue backward (activation and PixelShuffle), add, accumulate, casts
     for act, ps in ((1, 1), (2, 2), (2, 3)):
         Cq = 8
@@ -1335,17 +1351,21 @@ def check_bf16_ops_vs_fp32_kernels(device, seed=1):
     return out
 
 
-def check_bf16_c3_full_frame(device="cuda"):
+def check_bf16_c3_full_frame(device="cuda", scale=4, H=256, W=320):
     """BASELINE.json configs[2] at its full frame size (x4 net, nb=16, L=256, DGBs 0..13, one 256x320 LR frame ->
-    1024x1280) on the bf16 path, against the fp32 CPU oracle (forward: north_star's reduced-precision bar,
-    |PSNR(out_bf16, GT) - PSNR(out_oracle, GT)| <= 0.02 dB) and against this repo's fp32 HIP path on the same weights
-    (harness-loss gradients: relative L2 and cosine, gated at ~3x / well below the values measured on the MI355X)."""
-    case = dict(name="c3", scale=4, which=list(range(14)), L=256, nb=16, B=1, H=256, W=320)
+    1024x1280) on the bf16 path - and, with scale=8 / 128x160, configs[3]'s per-GPU network - against the fp32 CPU oracle
+    (forward: north_star's reduced-precision bar, |PSNR(out_bf16, GT) - PSNR(out_oracle, GT)| <= 0.02 dB) and against
+    this repo's fp32 HIP path on the same weights (harness-loss gradients: relative L2 and cosine, gated at ~3x / well
+    below the values measured on the MI355X)."""
+    case = dict(name="c3", scale=scale, which=list(range(14)), L=256, nb=16, B=1, H=H, W=W)
     net, cfg = build_net(case, device)
-    lq, gt, dm, mk = synth.closed_form_batch(0, 1, case["H"], case["W"], 4)
+    lq, gt, dm, mk = synth.closed_form_batch(0, 1, case["H"], case["W"], scale)
     sd = _oracle_sd(net)
     with torch.no_grad():
         ref = O.depthnet_forward(sd, cfg, lq, dm, mk)
+        with O.bf16_storage():                      # CPU model of the same rounding points (oracle, test infrastructure)
+            ref_model = O.depthnet_forward(sd, cfg, lq, dm, mk)
+    psnr_model = O.psnr_255(ref_model, ref)
     lqd, gtd, dmd, mkd = [t.to(device) for t in (lq, gt, dm, mk)]
     res = {}
     for dt in (torch.float32, BF16):
@@ -1374,16 +1394,19 @@ def check_bf16_c3_full_frame(device="cuda"):
         dot += (a * b).sum().item()
         nb += b.pow(2).sum().item()
     rel, cos = math.sqrt(num / den), dot / math.sqrt(den * nb)
-    out = dict(dpsnr_fp32=dpsnr32, dpsnr_bf16=dpsnr16, psnr_bf16_vs_oracle=psnr16,
+    out = dict(dpsnr_fp32=dpsnr32, dpsnr_bf16=dpsnr16, psnr_bf16_vs_oracle=psnr16, psnr_cpu_bf16_model_vs_oracle=psnr_model,
                max_err_bf16=(sr16 - ref).abs().max().item(), loss_grad_rel_l2_bf16_vs_fp32=rel, loss_grad_cosine=cos,
                l_pix=(res[torch.float32][1], res[BF16][1]), l_dyn=(res[torch.float32][2], res[BF16][2]))
-    print("bf16 c3 full frame:", out)
+    print("bf16 full frame x%d %dx%d:" % (scale, H, W), out)
     assert dpsnr32 <= 1e-3, dpsnr32                 # the fp32 path: north_star's fp32 bar
     assert dpsnr16 <= 0.02, dpsnr16                 # the bf16 path: north_star's reduced-precision bar
     # 13 DGBs deep, every stored activation carries 8 significant bits and each block's two instance norms re-amplify
     # the noise of the one before: measured 32.3 dB against the fp32 oracle's image on the MI355X (45 .. 48 dB for the
     # two-block golden cases); the floor only catches a broken kernel
     assert psnr16 >= 28.0, psnr16
+    # ... and it is the price of the storage format, not of these kernels: a CPU restatement that rounds at the same
+    # points (oracle.bf16_storage) lands within 3 dB of the HIP path's distance to the fp32 image
+    assert psnr16 >= psnr_model - 3.0, (psnr16, psnr_model)
     assert rel <= BF16_C3_GRAD_GATE[0] and cos >= BF16_C3_GRAD_GATE[1], (rel, cos)
     return out
 

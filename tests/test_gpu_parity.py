@@ -205,3 +205,9 @@ def test_bf16_depthnet(name):
 @pytest.mark.gpu
 def test_bf16_c3_full_frame():
     print(pc.check_bf16_c3_full_frame("cuda"))
+
+
+@pytest.mark.gpu
+def test_bf16_c4_full_frame():
+    """BASELINE configs[3]'s per-GPU network (x8, nb=16, L=256, 128x160 LR) on the bf16 path."""
+    print(pc.check_bf16_c3_full_frame("cuda", scale=8, H=128, W=160))
