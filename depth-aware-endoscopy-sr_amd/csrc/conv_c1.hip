@@ -1,5 +1,7 @@
 // conv_c1.hip — 3x3 convolution of a ONE-channel image (the depth map) to Cout channels with fused ReLU:
-// SEAN.mlp_mask (normalization.py:36-40,61), forward and weight/bias gradient.  There is no reduction over
+// SEAN.mlp_mask (normalization.py:36-40,61), forward and weight/bias gradient - and, as the CIN = 3 instantiation, of
+// the 3-channel LR frame: the encoder's first layer (sftmd_arch.py:745, weight-normed 3 -> 32, LeakyReLU), which ran on
+// the generic direct kernels (1.7 ms forward, 6.3 ms weight gradient at 32 frames of 256x320).  There is next to no reduction over
 // input channels, so this is HBM-bound elementwise work: the forward writes B*H*W*Cout floats, the backward
 // reads the incoming gradient and the saved activation once (ReLU backward fused) and reduces over pixels.
 // Lane layout: a lane owns 4 consecutive output channels (float4), 256-byte runs per 16 lanes.
@@ -12,40 +14,45 @@
 // pixels with plain 32-bit increments.  (The first version derived (b, y, x) of every pixel from a flat 64-bit index -
 // three 64-bit divisions per pixel - and fetched the 9 taps with predicated global loads: VALU-bound at 1.7 TB/s.)
 #define C1_MAXW 4096
+// three image rows around row y, [3][(W+2)*CIN] (NHWC input: a row is W*CIN consecutive floats), zero padded
+template <int CIN>
 __device__ __forceinline__ void c1_stage_rows(const float* __restrict__ x, float* sRow, int b, int y, int H, int W) {
-    const float* xb = x + (size_t)b * H * W;
-    for (int i = threadIdx.x; i < 3 * (W + 2); i += 256) {
-        const int r = i / (W + 2), c = i - r * (W + 2);
-        const int iy = y + r - 1, ix = c - 1;
-        sRow[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[(size_t)iy * W + ix] : 0.f;
+    const float* xb = x + (size_t)b * H * W * CIN;
+    const int RW = (W + 2) * CIN;
+    for (int i = threadIdx.x; i < 3 * RW; i += 256) {
+        const int r = i / RW, c = i - r * RW;
+        const int iy = y + r - 1, ix = c / CIN - 1;
+        sRow[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((size_t)iy * W + ix) * CIN + c % CIN] : 0.f;
     }
 }
 
 // T = storage type of the Cout-channel activation (y, dy, yact): float or bf16_t; the depth map and the kernel are fp32
-template <typename T>
+template <typename T, int CIN>
 __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int B,
                                                         int H, int W, int Cout, int act) {
     DASR_DYN_SMEM(smem);
-    float* sRow = (float*)smem;                    // [3][W+2]
+    float* sRow = (float*)smem;                    // [3][(W+2)*CIN]
     const int nq = Cout / 4;                       // channel quads
     const int q = threadIdx.x % nq, pl = threadIdx.x / nq, npl = 256 / nq;
-    float4 wt[9];
+    constexpr int NT = 9 * CIN;                    // (tap, ci) terms: HWIO kernel rows
+    const int RW = (W + 2) * CIN;
+    float4 wt[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t] = *(const float4*)(w + (size_t)t * Cout + 4 * q);
+    for (int t = 0; t < NT; ++t) wt[t] = *(const float4*)(w + (size_t)t * Cout + 4 * q);
     const float4 bv = bias ? *(const float4*)(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
         const int b = row / H, py = row - b * H;
         __syncthreads();
-        c1_stage_rows(x, sRow, b, py, H, W);
+        c1_stage_rows<CIN>(x, sRow, b, py, H, W);
         __syncthreads();
         if (pl >= npl) continue;
         T* yrow = y + ((size_t)row * W) * Cout + 4 * q;
         for (int px = pl; px < W; px += npl) {
             float4 acc = bv;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float d = sRow[(t / 3) * (W + 2) + px + t % 3];
+            for (int t = 0; t < NT; ++t) {     // t = (kh*3 + kw)*CIN + ci
+                const float d = sRow[(t / (3 * CIN)) * RW + (px + (t / CIN) % 3) * CIN + t % CIN];
                 acc.x = fmaf(d, wt[t].x, acc.x); acc.y = fmaf(d, wt[t].y, acc.y);
                 acc.z = fmaf(d, wt[t].z, acc.z); acc.w = fmaf(d, wt[t].w, acc.w);
             }
@@ -57,23 +64,25 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict_
 }
 
 // dw[tap][co] = sum_p x[p+tap] * dconv[p][co], dbias[co] = sum_p dconv[p][co], dconv = dy * act'(y)
-template <typename T>
+template <typename T, int CIN>
 __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restrict__ x, const T* __restrict__ dy,
                                                           const T* __restrict__ yact, float* __restrict__ dw,
                                                           float* __restrict__ dbias, int B, int H, int W, int Cout,
                                                           int act) {
     DASR_DYN_SMEM(smem);
-    float* red = (float*)smem;                     // [256][40] partials
-    float* sRow = red + 256 * 40;                  // [3][W+2]
+    constexpr int NT = 9 * CIN;                    // (tap, ci) terms; accumulator NT is the bias gradient
+    const int RW = (W + 2) * CIN;
+    float* red = (float*)smem;                     // [256][4] partials of ONE term at a time
+    float* sRow = red + 256 * 4;                   // [3][(W+2)*CIN]
     const int nq = Cout / 4;
     const int q = threadIdx.x % nq, pl = threadIdx.x / nq, npl = 256 / nq;
-    float4 acc[10];
+    float4 acc[NT + 1];
 #pragma unroll
-    for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < NT + 1; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
         const int b = row / H, py = row - b * H;
         __syncthreads();
-        c1_stage_rows(x, sRow, b, py, H, W);
+        c1_stage_rows<CIN>(x, sRow, b, py, H, W);
         __syncthreads();
         if (pl >= npl) continue;
         const T* grow = dy + ((size_t)row * W) * Cout + 4 * q;
@@ -100,27 +109,30 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restric
                     g.x *= dasr_act_grad_from_out(yq[u].x, act); g.y *= dasr_act_grad_from_out(yq[u].y, act);
                     g.z *= dasr_act_grad_from_out(yq[u].z, act); g.w *= dasr_act_grad_from_out(yq[u].w, act);
                 }
-                acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
+                acc[NT].x += g.x; acc[NT].y += g.y; acc[NT].z += g.z; acc[NT].w += g.w;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float d = sRow[(t / 3) * (W + 2) + pc + t % 3];
+                for (int t = 0; t < NT; ++t) {
+                    const float d = sRow[(t / (3 * CIN)) * RW + (pc + (t / CIN) % 3) * CIN + t % CIN];
                     acc[t].x = fmaf(d, g.x, acc[t].x); acc[t].y = fmaf(d, g.y, acc[t].y);
                     acc[t].z = fmaf(d, g.z, acc[t].z); acc[t].w = fmaf(d, g.w, acc[t].w);
                 }
             }
         }
     }
-    // reduce over the pixel lanes of the workgroup, then one float atomic per output per workgroup
-    __syncthreads();
+    // reduce over the pixel lanes of the workgroup (one term at a time through 4 KB of LDS), then one float atomic per
+    // output per workgroup
 #pragma unroll
-    for (int t = 0; t < 10; ++t) *(float4*)(red + (threadIdx.x * 10 + t) * 4) = acc[t];
-    __syncthreads();
-    for (int e = threadIdx.x; e < 10 * Cout; e += 256) {
-        const int t = e / Cout, co = e % Cout, qq = co / 4, j = co % 4;
-        float s = 0.f;
-        for (int l = 0; l < npl; ++l) s += red[((l * nq + qq) * 10 + t) * 4 + j];
-        if (t < 9) atomicAdd(&dw[(size_t)t * Cout + co], s);
-        else if (dbias) atomicAdd(&dbias[co], s);
+    for (int t = 0; t < NT + 1; ++t) {
+        __syncthreads();
+        *(float4*)(red + threadIdx.x * 4) = acc[t];
+        __syncthreads();
+        for (int co = threadIdx.x; co < Cout; co += 256) {
+            const int qq = co / 4, j = co % 4;
+            float s = 0.f;
+            for (int l = 0; l < npl; ++l) s += red[(l * nq + qq) * 4 + j];
+            if (t < NT) atomicAdd(&dw[(size_t)t * Cout + co], s);
+            else if (dbias) atomicAdd(&dbias[co], s);
+        }
     }
 }
 
@@ -131,15 +143,17 @@ __global__ void __launch_bounds__(256) k_c1_zero(float* __restrict__ dw, int nw,
 }
 
 bool conv_c1_supported(const ConvGeom& g) {
-    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && g.Cin == 1 && (g.Cout % 4) == 0 &&
-           g.Cout <= 1024 && (256 % (g.Cout / 4)) == 0 && g.H == g.Ho && g.W == g.Wo && g.W <= C1_MAXW;
+    return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin == 1 || g.Cin == 3) &&
+           (g.Cout % 4) == 0 && g.Cout <= (g.Cin == 1 ? 1024 : 256) && (256 % (g.Cout / 4)) == 0 && g.H == g.Ho &&
+           g.W == g.Wo && g.W <= C1_MAXW;
 }
 template <typename T>
 static int conv_c1_fwd_impl(const ConvGeom& g, const float* x, const float* w, const float* bias, T* y, int act, void* stream) {
     unsigned grid = (unsigned)(g.B * g.H);
     if (grid > 256 * 8) grid = 256 * 8;
-    DASR_LAUNCH((k_conv3x3_c1_fwd<T>), dim3(grid), dim3(256), sizeof(float) * 3 * (g.W + 2), stream, x, w, bias, y, g.B, g.H,
-                g.W, g.Cout, act);
+    const size_t lds = sizeof(float) * 3 * (g.W + 2) * g.Cin;
+    if (g.Cin == 3) DASR_LAUNCH((k_conv3x3_c1_fwd<T, 3>), dim3(grid), dim3(256), lds, stream, x, w, bias, y, g.B, g.H, g.W, g.Cout, act);
+    else            DASR_LAUNCH((k_conv3x3_c1_fwd<T, 1>), dim3(grid), dim3(256), lds, stream, x, w, bias, y, g.B, g.H, g.W, g.Cout, act);
     DASR_RETURN_LAUNCH_STATUS();
 }
 int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream) {
@@ -153,12 +167,14 @@ template <typename T>
 static int conv_c1_wgrad_impl(const ConvGeom& g, const float* x, const T* dy, const T* yact, int act, float* dw, float* dbias,
                               void* stream) {
     // one launch clears both accumulators (two memsets were two more dispatches on a 130 us kernel)
-    DASR_LAUNCH(k_c1_zero, dim3(dasr_cdiv((size_t)10 * g.Cout, 256)), dim3(256), 0, stream, dw, 9 * g.Cout, dbias, g.Cout);
+    DASR_LAUNCH(k_c1_zero, dim3(dasr_cdiv((size_t)(9 * g.Cin + 1) * g.Cout, 256)), dim3(256), 0, stream, dw, 9 * g.Cin * g.Cout,
+                dbias, g.Cout);
     unsigned grid = (unsigned)(g.B * g.H);
     const unsigned cap = sizeof(T) == 2 ? 768 : 512;   // fp32: two workgroups per CU (more only adds float atomics at the end, measured); bf16: three
     if (grid > cap) grid = cap;
-    DASR_LAUNCH((k_conv3x3_c1_wgrad<T>), dim3(grid), dim3(256), sizeof(float) * (256 * 40 + 3 * (g.W + 2)), stream, x, dy, yact,
-                dw, dbias, g.B, g.H, g.W, g.Cout, act);
+    const size_t lds = sizeof(float) * (256 * 4 + 3 * (g.W + 2) * g.Cin);
+    if (g.Cin == 3) DASR_LAUNCH((k_conv3x3_c1_wgrad<T, 3>), dim3(grid), dim3(256), lds, stream, x, dy, yact, dw, dbias, g.B, g.H, g.W, g.Cout, act);
+    else            DASR_LAUNCH((k_conv3x3_c1_wgrad<T, 1>), dim3(grid), dim3(256), lds, stream, x, dy, yact, dw, dbias, g.B, g.H, g.W, g.Cout, act);
     DASR_RETURN_LAUNCH_STATUS();
 }
 int conv_c1_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* yact, int act, float* dw, float* dbias,

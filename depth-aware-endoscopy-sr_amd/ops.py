@@ -298,7 +298,7 @@ def conv2d_wgrad_act(x, dy, y, w_shape, act, stride=1, pad=1, transposed=False, 
         return dw, db
     nbytes = lib.dasr_conv2d_wgrad_workspace(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, int(transposed))
     ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
-    fused = (Cin == 1 and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not transposed)
+    fused = (Cin in (1, 3) and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not transposed)
     scratch = None if fused else torch.empty_like(y)
     dw = empty(w_shape, x)
     db = empty((Cout,), x) if want_bias else None
