@@ -23,7 +23,6 @@
 // gfx950's transposing LDS read (cdna_hip_programming.md T10): two of them per operand.  Pixel strides of 64 or 192
 // bytes make those reads conflict-free.  Accumulators stay resident over a strip of tiles; slabs + the fixed-order
 // reduction of conv_mfma.hip (k_wgrad_reduce) finish the sum in fp32.
-#include <cstdlib>
 #include "bf16.h"
 #include "conv_kernels.h"
 
@@ -49,7 +48,13 @@ struct ConvBf16Args {
 // kernel (operand reads + staging writes were 82 % of the CU's LDS cycles at NW = 4 / NT = 2: 868 TF on 128 -> 128).
 // CB_MTW = tile rows per wave: 2, or 4 (32-row tiles with NW = 8: 6 operand reads per 8 MFMAs, the kernel slice staged
 // once per 1024 pixels - LDS cycles per MFMA drop from 82 % to 56 % of the pipe time; 128 accumulator registers).
-template <int NT, int WMODE, int NW, int CB_MTW, int CK>
+// TD ("transposed D"): the MFMA operands swapped - D^T = W^T . X^T (both fragments have the same register layout) - puts the
+// PIXEL on the lane and 4 consecutive output channels in each group of 4 registers, so bias / residual / activation / store
+// can go straight from registers, 8 bytes per lane, no LDS.  Measured and NOT used: every store instruction then touches 32
+// different cache lines (a lane per pixel), and the kernel was 15-30 % SLOWER than with the LDS-transposing epilogue
+// (128 -> 128: 1014 vs 880 us; 64 -> 64: 366 vs 287 us).  For scale: with the epilogue compiled out entirely (garbage results)
+// the same kernels take 647 / 162 us - the main loop runs at 1.2-1.3 PF, the epilogue is 26 % / 44 % of the kernel.
+template <int NT, int WMODE, int NW, int CB_MTW, int CK, bool TD>
 __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
     DASR_DYN_SMEM(smem);
     constexpr int NTHR = 64 * NW, CB_TH = CB_MTW * NW, CB_HALO_H = CB_TH + 2;
@@ -148,7 +153,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
             for (int m = 0; m < CB_MTW; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], Bf[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = TD ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[n], A[m], acc[m][n], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], Bf[n], acc[m][n], 0, 0, 0);
         };
         if (NT * CB_MTW < 8) {
             bf16x8 A0[CB_MTW], B0[NT], A1[CB_MTW], B1[NT];
@@ -173,15 +179,92 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
     }
 
     // ---- epilogue
+    if (TD) {
+        // lane (li = pixel of the tile row, lh): registers 4g .. 4g+3 of acc[m][n] = channels n0 + 32n + 8g + 4lh .. +3
+        const bool is_relu = a.act == DASR_ACT_RELU;
+        const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
+        const bool xin = x0 + li < a.W;
+#pragma unroll
+        for (int m = 0; m < CB_MTW; ++m) {
+            const int gy = y0 + CB_MTW * wv + m;
+            if (gy >= a.H || !xin) continue;
+            bf16_t* yp = a.y + (((size_t)b * a.H + gy) * a.W + x0 + li) * a.Cout + n0 + 4 * lh;
+            const bf16_t* rp = a.residual ? a.residual + (((size_t)b * a.H + gy) * a.W + x0 + li) * a.Cout + n0 + 4 * lh : nullptr;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bf16x4 rv[4], av[4];
+                if (rp) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rv[g] = *(const bf16x4*)(rp + 32 * n + 8 * g);
+                }
+                if (a.accumulate) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) av[g] = *(const bf16x4*)(yp + 32 * n + 8 * g);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = a.bias ? *(const float4*)(a.bias + n0 + 32 * n + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float o[4] = {acc[m][n][4 * g] + bv.x, acc[m][n][4 * g + 1] + bv.y, acc[m][n][4 * g + 2] + bv.z,
+                                  acc[m][n][4 * g + 3] + bv.w};
+                    bf16x4 ov;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (rp) o[t] += dasr_bf2f(rv[g][t]);
+                        const float neg = is_relu ? 0.f : o[t] * slope;
+                        o[t] = o[t] > 0.f ? o[t] : neg;
+                        if (a.accumulate) o[t] += dasr_bf2f(av[g][t]);
+                        ov[t] = dasr_f2bf(o[t]);
+                    }
+                    *(bf16x4*)(yp + 32 * n + 8 * g) = ov;
+                }
+            }
+        }
+        return;
+    }
     const int ps = a.ps_r, rr = ps * ps;
     const bool fast = x0 + CB_TW <= a.W && (ps == 1 || (ps == 2 && a.residual == nullptr && !a.accumulate));
     if (fast) {
-        // per wave: [32 pixels][NTILE + 4] fp32 (the +4 keeps the 16-byte alignment and spreads the rows over the banks)
-        constexpr int EP = NTILE + 4;
-        __syncthreads();                       // every wave is done with the last chunk's operands
-        float* sE = (float*)smem + wv * (32 * EP);
+        // Every wave passes its rows through its OWN slice of LDS, so the hand-off between its lanes needs no s_barrier,
+        // only program order (DASR_WAVE_SYNC).  One barrier first: every wave must be done with the last chunk's operands.
+        __syncthreads();
         const bool is_relu = a.act == DASR_ACT_RELU;
         const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
+        if (ps == 1 && a.residual == nullptr && !a.accumulate) {
+            // plain layers (the DGB convolutions, gamma_o|beta_o, most dgrads): bias + activation in the accumulator
+            // layout, rounded to bf16 BEFORE the transposition: half the LDS bytes, and the read-back is the store data
+            constexpr int EPH = NTILE + 8;                            // bf16 elements per pixel row (16-byte aligned rows)
+            bf16_t* sH = (bf16_t*)smem + wv * (32 * EPH);
+#pragma unroll
+            for (int m = 0; m < CB_MTW; ++m) {
+                const int gy = y0 + CB_MTW * wv + m;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float bv = a.bias ? a.bias[n0 + 32 * n + li] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[m][n][r] + bv;
+                        const float neg = is_relu ? 0.f : v * slope;
+                        v = v > 0.f ? v : neg;
+                        sH[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPH + 32 * n + li] = dasr_f2bf(v);
+                    }
+                }
+                DASR_WAVE_SYNC();
+                if (gy < a.H) {
+                    constexpr int GP = NTILE / 8;
+#pragma unroll
+                    for (int u = 0; u < (32 * GP) / 64; ++u) {
+                        const int v = lane + 64 * u, p = v / GP, cg = v % GP;
+                        const bf16x8 ov = *(const bf16x8*)(sH + p * EPH + 8 * cg);
+                        *(bf16x8*)(a.y + (((size_t)b * a.H + gy) * a.W + x0 + p) * a.Cout + n0 + 8 * cg) = ov;
+                    }
+                }
+                DASR_WAVE_SYNC();                  // the slice is rewritten by the next row
+            }
+            return;
+        }
+        // per wave: [32 pixels][NTILE + 4] fp32 (the +4 keeps the 16-byte alignment and spreads the rows over the banks)
+        constexpr int EP = NTILE + 4;
+        float* sE = (float*)smem + wv * (32 * EP);
 #pragma unroll
         for (int m = 0; m < CB_MTW; ++m) {
             const int gy = y0 + CB_MTW * wv + m;
@@ -192,7 +275,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
                 for (int r = 0; r < 16; ++r)
                     sE[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * n + li] = acc[m][n][r] + bv;
             }
-            __syncthreads();
+            DASR_WAVE_SYNC();
             if (gy < a.H) {
                 if (ps == 1) {
                     constexpr int GP = NTILE / 8;                 // 8-channel groups per pixel
@@ -245,7 +328,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
                     }
                 }
             }
-            __syncthreads();                   // the slice is rewritten by the next row
+            DASR_WAVE_SYNC();                      // the slice is rewritten by the next row
         }
         return;
     }
@@ -297,26 +380,20 @@ bool conv_bf16_dgrad_supported(const ConvGeom& g) {
            (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
 }
 
-// Tile variants (tools/bench_ops_bf16.py, profiles/r02_conv_bf16_variants.txt).  DASR_CB_MTW=4 is an experiment knob of the
-// benchmark tool only.
+// Tile variants measured on the MI355X at the x4 / B=32 shapes (tools/bench_ops_bf16.py, profiles/r02_conv_bf16_variants.txt):
+// 8-row tiles with two 256-thread workgroups per CU beat one 512-thread workgroup with 16- or 32-row tiles, and two rows x
+// two N tiles per wave beat 128-accumulator register tiles (their lower LDS traffic did not pay: the limiter was the
+// epilogue, see TD above).
 template <int WMODE>
 static int launch_conv_bf16(ConvBf16Args& a, void* stream) {
     const int NT = (a.Cout % 64) == 0 ? 2 : 1;
-    int MTW = 2;
-#if DASR_DEVICE_BUILD
-    if (const char* e = getenv("DASR_CB_MTW"))
-        if (atoi(e) == 4 && NT == 2 && (a.W % CB_TW) == 0 && (a.H % 32) == 0 &&
-            (a.ps_r == 1 || (a.ps_r == 2 && !a.residual && !a.accumulate)))
-            MTW = 4;
-#endif
-    const int NW = MTW == 4 ? 8 : 4, TH = MTW * NW, CK = MTW == 4 ? 16 : 32;
+    const int TH = 8;
     const int tiles = ((a.W + CB_TW - 1) / CB_TW) * ((a.H + TH - 1) / TH);
     const int G8 = (tiles * a.B + 7) / 8 * 8;                 // pixel tiles, padded to whole rounds over the 8 XCDs
     const dim3 grid(G8 * (a.Cout / (32 * NT)));
-    const size_t lds = conv_bf16_lds(NT, NW, MTW, CK);
-    if (MTW == 4)     DASR_LAUNCH((k_conv3x3_bf16<2, WMODE, 8, 4, 16>), grid, dim3(512), lds, stream, a);
-    else if (NT == 2) DASR_LAUNCH((k_conv3x3_bf16<2, WMODE, 4, 2, 32>), grid, dim3(256), lds, stream, a);
-    else              DASR_LAUNCH((k_conv3x3_bf16<1, WMODE, 4, 2, 32>), grid, dim3(256), lds, stream, a);
+    const size_t lds = conv_bf16_lds(NT, 4, 2, 32);
+    if (NT == 2) DASR_LAUNCH((k_conv3x3_bf16<2, WMODE, 4, 2, 32, false>), grid, dim3(256), lds, stream, a);
+    else         DASR_LAUNCH((k_conv3x3_bf16<1, WMODE, 4, 2, 32, false>), grid, dim3(256), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
 }
 

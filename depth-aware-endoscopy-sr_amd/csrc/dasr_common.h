@@ -14,6 +14,7 @@
 #define DASR_DEVICE_BUILD 0
 #define DASR_UNIFORM(x) (x)
 #define DASR_SCHED_BARRIER() ((void)0)
+#define DASR_WAVE_SYNC() hipemu::wave_barrier()
 #else
 #include <hip/hip_runtime.h>
 #define DASR_LAUNCH(kernel, grid, block, shmem, stream, ...) \
@@ -23,6 +24,10 @@
 // a value the program knows to be the same in every lane of the wave: move it to an SGPR
 #define DASR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define DASR_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// Ordering point between LDS accesses of ONE wave that communicate across its lanes (wave-private LDS slices): the
+// hardware executes a wave's DS instructions in issue order, so no s_barrier is needed - only that the compiler keeps the
+// program order (fence) and, on the CPU emulator, that the wave's fibers meet
+#define DASR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
