@@ -204,6 +204,19 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
         CM_T_MARK(5);
     }
     // ---- epilogue
+#ifdef DASR_CM_NOEPI     // timing experiment only: what the epilogue costs (garbage results)
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+        if (s == 12345.678f) a.y[(size_t)blockIdx.x * 16 + wv] = s;
+        return;
+    }
+#endif
     const int rr = a.ps_r * a.ps_r;
     // Fast path (full-width tiles, the usual case): every address is "scalar row base + scalar pixel offset + one
     // per-lane 32-bit byte offset", the optional residual / accumulate operands are fetched for all 16 pixels of a

@@ -701,12 +701,25 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
         }
     };
     auto f4 = [](auto v) { return sean_f4(v); };
+    // the tile's region bytes (with halo; K = "no region" outside the image) travel with the prefetch too: one byte per
+    // thread, loaded a tile ahead - staged after the barrier they cost a full global-load latency per tile (one
+    // workgroup per CU: nothing else to hide it)
+    constexpr int NR = (SB_TH + 2) * (SF_TW + 2);                 // <= 204 bytes
+    auto issue_r = [&](int tile) {
+        const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
+        const int i = (int)threadIdx.x < NR ? (int)threadIdx.x : 0;
+        const int gy = y0 + i / (SF_TW + 2) - 1, gx = x0 + i % (SF_TW + 2) - 1;
+        unsigned char v = (unsigned char)g.K;
+        if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = region[((size_t)b * g.H + gy) * g.W + gx];
+        return v;
+    };
     SeanBwdLoads<T, NST> cur;
-    if ((int)blockIdx.x < ntiles) issue(blockIdx.x, cur);
+    unsigned char rcur = (unsigned char)g.K;
+    if ((int)blockIdx.x < ntiles) { issue(blockIdx.x, cur); rcur = issue_r(blockIdx.x); }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
         __syncthreads();                          // previous phase 2 is done with sG / sR
-        sean_stage_R(g, region, sR, b, y0, x0, SB_TH);
+        if ((int)threadIdx.x < NR) sR[threadIdx.x] = rcur;
         __syncthreads();
         // ---- phase 1
         {
@@ -766,7 +779,10 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
                 DASR_SCHED_BARRIER();              // one step's gather rows at a time (256-VGPR budget)
             }
         }
-        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, cur);    // in flight during the matrix phase
+        if (tile + (int)gridDim.x < ntiles) {     // in flight during the matrix phase
+            issue(tile + gridDim.x, cur);
+            rcur = issue_r(tile + gridDim.x);
+        }
         __syncthreads();
         // ---- phase 2: one-hot(region) x G, 32 pixels per MFMA (one tile row per K step)
         {

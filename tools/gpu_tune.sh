@@ -1,4 +1,9 @@
-O=gpurun_out/r2q; mkdir -p $O
-python -m pytest tests/test_gpu_parity.py -q -x -k "bf16" 2>&1 | tail -2
-python tools/bench_ops_bf16.py --only conv 2>&1 | grep "conv3x3" | tee $O/conv_ep.txt
-python bench.py --config c3 --steps 3 --warmup 1 > $O/bench_c3.json 2> $O/bench_c3.err; cut -c1-200 $O/bench_c3.json
+O=gpurun_out/r2s; mkdir -p $O
+cd depth-aware-endoscopy-sr_amd && python - <<'PY'
+import sys; sys.path.insert(0, "..")
+import dasr_amd
+from dasr_amd import build
+build.build_hip(force=True, verbose=False, extra_flags=["-DDASR_CM_NOEPI"])
+PY
+cd ..
+python tools/bench_ops.py --batch 16 --only conv 2>&1 | grep "conv3x3" | tee $O/noepi.txt
