@@ -51,6 +51,17 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float4 v) {
     o[0] = dasr_f2bf(v.x); o[1] = dasr_f2bf(v.y); o[2] = dasr_f2bf(v.z); o[3] = dasr_f2bf(v.w);
     *(bf16x4*)p = o;
 }
+// the same 4 elements left unconverted (software-pipelined loops hold the next trip's loads in this form)
+template <typename T> struct raw4;
+template <> struct raw4<float> { typedef float4 type; };
+template <> struct raw4<bf16_t> { typedef bf16x4 type; };
+__device__ __forceinline__ float4 ld4_raw(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ bf16x4 ld4_raw(const bf16_t* p) { return *(const bf16x4*)p; }
+template <typename T> __device__ __forceinline__ float4 cvt4(typename raw4<T>::type v);
+template <> __device__ __forceinline__ float4 cvt4<float>(float4 v) { return v; }
+template <> __device__ __forceinline__ float4 cvt4<bf16_t>(bf16x4 v) {
+    return make_float4(dasr_bf2f(v[0]), dasr_bf2f(v[1]), dasr_bf2f(v[2]), dasr_bf2f(v[3]));
+}
 // streaming variants (read once / written once: keep them out of the caches)
 template <typename T> __device__ __forceinline__ float4 ld4_nt(const T* p);
 template <> __device__ __forceinline__ float4 ld4_nt<float>(const float* p) {

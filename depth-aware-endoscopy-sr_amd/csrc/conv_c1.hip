@@ -15,14 +15,26 @@
 // three 64-bit divisions per pixel - and fetched the 9 taps with predicated global loads: VALU-bound at 1.7 TB/s.)
 #define C1_MAXW 4096
 // three image rows around row y, [3][(W+2)*CIN] (NHWC input: a row is W*CIN consecutive floats), zero padded
+// Four loads per thread are issued before the first LDS write, from clamped addresses with the padding selected in
+// afterwards: the plain `lds[i] = inside ? x[..] : 0` loop is one exec-masked global round trip per element per thread.
 template <int CIN>
 __device__ __forceinline__ void c1_stage_rows(const float* __restrict__ x, float* sRow, int b, int y, int H, int W) {
     const float* xb = x + (size_t)b * H * W * CIN;
-    const int RW = (W + 2) * CIN;
-    for (int i = threadIdx.x; i < 3 * RW; i += 256) {
-        const int r = i / RW, c = i - r * RW;
-        const int iy = y + r - 1, ix = c / CIN - 1;
-        sRow[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((size_t)iy * W + ix) * CIN + c % CIN] : 0.f;
+    const int RW = (W + 2) * CIN, n = 3 * RW;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+        float v[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u < n ? i0 + 256 * u : 0;
+            const int r = i / RW, c = i - r * RW;
+            const int iy = y + r - 1, ix = c / CIN - 1;
+            in[u] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            v[u] = xb[in[u] ? ((size_t)iy * W + ix) * CIN + c % CIN : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 256 * u < n) sRow[i0 + 256 * u] = in[u] ? v[u] : 0.f;
     }
 }
 
@@ -41,12 +53,15 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < NT; ++t) wt[t] = *(const float4*)(w + (size_t)t * Cout + 4 * q);
     const float4 bv = bias ? *(const float4*)(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // ReLU: 0 (not 0 * v: keeps +0 and does not pass NaN through the multiply), LeakyReLU: 0.2 v, none: v
+    const float slope = act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
+    const bool relu = act == DASR_ACT_RELU;
+    auto neg = [&](float v) { return relu ? 0.f : slope * v; };
     for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
         const int b = row / H, py = row - b * H;
         __syncthreads();
         c1_stage_rows<CIN>(x, sRow, b, py, H, W);
         __syncthreads();
-        if (pl >= npl) continue;
         T* yrow = y + ((size_t)row * W) * Cout + 4 * q;
         for (int px = pl; px < W; px += npl) {
             float4 acc = bv;
@@ -56,15 +71,23 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict_
                 acc.x = fmaf(d, wt[t].x, acc.x); acc.y = fmaf(d, wt[t].y, acc.y);
                 acc.z = fmaf(d, wt[t].z, acc.z); acc.w = fmaf(d, wt[t].w, acc.w);
             }
-            acc.x = dasr_act(acc.x, act); acc.y = dasr_act(acc.y, act);
-            acc.z = dasr_act(acc.z, act); acc.w = dasr_act(acc.w, act);
+            // branch-free: the activation kind is one uniform slope (ReLU 0, LeakyReLU 0.2, none 1)
+            acc.x = acc.x > 0.f ? acc.x : neg(acc.x); acc.y = acc.y > 0.f ? acc.y : neg(acc.y);
+            acc.z = acc.z > 0.f ? acc.z : neg(acc.z); acc.w = acc.w > 0.f ? acc.w : neg(acc.w);
             st4(yrow + (size_t)px * Cout, acc);
         }
     }
 }
 
 // dw[tap][co] = sum_p x[p+tap] * dconv[p][co], dbias[co] = sum_p dconv[p][co], dconv = dy * act'(y)
-template <typename T, int CIN>
+//
+// HASY: the saved activation is read and its derivative applied (a template parameter, and the derivative a select
+// against one uniform slope: with `yact ? load : 1` and the activation kind tested per element the compiler put every y
+// load in its own exec-masked block followed by s_waitcnt vmcnt(0) - eight serial round trips per trip - and several
+// scalar branches per element: 559 us for 32 frames of 256x320 in bf16, 2.4 TB/s).  Loads are unconditional (clamped
+// pixel, contribution zeroed) and software-pipelined: the next trip's 2*NPX loads - of the next ROW when the row is
+// done, the addresses do not depend on the staged depth rows - are in flight while this trip is reduced.
+template <typename T, int CIN, bool HASY>
 __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restrict__ x, const T* __restrict__ dy,
                                                           const T* __restrict__ yact, float* __restrict__ dw,
                                                           float* __restrict__ dbias, int B, int H, int W, int Cout,
@@ -76,45 +99,65 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_wgrad(const float* __restric
     float* sRow = red + 256 * 4;                   // [3][(W+2)*CIN]
     const int nq = Cout / 4;
     const int q = threadIdx.x % nq, pl = threadIdx.x / nq, npl = 256 / nq;
+    const float slope = act == DASR_ACT_RELU ? 0.f : act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
     float4 acc[NT + 1];
 #pragma unroll
     for (int t = 0; t < NT + 1; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+    // NPX pixels per trip; bf16 loads carry half the bytes, so twice the pixels keep the same bytes in flight
+    constexpr int NPX = sizeof(T) == 2 ? 8 : 4;
+    typedef typename raw4<T>::type Raw;
+    Raw gq[NPX], yq[NPX];
+    const int nrows = B * H, step = NPX * npl;
+    auto issue = [&](int row, int base) {
+        const size_t ro = ((size_t)row * W) * Cout + 4 * q;
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            const int px = base + pl + u * npl < W ? base + pl + u * npl : W - 1;
+            gq[u] = ld4_raw(dy + ro + (size_t)px * Cout);
+            if (HASY) yq[u] = ld4_raw(yact + ro + (size_t)px * Cout);
+        }
+    };
+    if ((int)blockIdx.x < nrows) issue(blockIdx.x, 0);
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int b = row / H, py = row - b * H;
         __syncthreads();
         c1_stage_rows<CIN>(x, sRow, b, py, H, W);
         __syncthreads();
-        if (pl >= npl) continue;
-        const T* grow = dy + ((size_t)row * W) * Cout + 4 * q;
-        const T* arow = yact ? yact + ((size_t)row * W) * Cout + 4 * q : nullptr;
-        // NPX pixels per trip: all 2*NPX loads are issued before the first is consumed (clamped addresses, contributions of
-        // pixels past the row end are zeroed).  bf16 loads carry half the bytes, so twice the pixels keep the same bytes
-        // in flight (0.56 -> see DESIGN section 4 for the measured rates)
-        constexpr int NPX = sizeof(T) == 2 ? 8 : 4;
-        for (int px0 = pl; px0 < W; px0 += NPX * npl) {
-            float4 gq[NPX], yq[NPX];
+        for (int base = 0; base < W; base += step) {
+            float4 g[NPX];
 #pragma unroll
             for (int u = 0; u < NPX; ++u) {
-                const int px = px0 + u * npl < W ? px0 + u * npl : W - 1;
-                gq[u] = ld4(grow + (size_t)px * Cout);
-                yq[u] = arow ? ld4(arow + (size_t)px * Cout) : make_float4(1.f, 1.f, 1.f, 1.f);
+                g[u] = cvt4<T>(gq[u]);
+                if (HASY) {
+                    const float4 yv = cvt4<T>(yq[u]);
+                    g[u].x *= yv.x > 0.f ? 1.f : slope; g[u].y *= yv.y > 0.f ? 1.f : slope;
+                    g[u].z *= yv.z > 0.f ? 1.f : slope; g[u].w *= yv.w > 0.f ? 1.f : slope;
+                }
+            }
+            // the registers are free again: next trip (same row, or the first of this workgroup's next row).  Issued
+            // unconditionally - after the very last trip it re-reads a trip of this row - because a branch around the loads
+            // makes the waitcnt pass assume the fewest outstanding loads at the join and wait for the NEW loads too.
+            {
+                int nb = base + step, nr = row;
+                if (nb >= W) {
+                    nb = 0;
+                    nr = row + (int)gridDim.x < nrows ? row + (int)gridDim.x : row;
+                }
+                DASR_SCHED_BARRIER();      // conversions above, loads here, the reduction below: otherwise the scheduler
+                issue(nr, nb);             // sinks the loads to the end of the trip and nothing is in flight during it
+                DASR_SCHED_BARRIER();
             }
 #pragma unroll
             for (int u = 0; u < NPX; ++u) {
-                const int px = px0 + u * npl;
-                float4 g = gq[u];
-                if (px >= W) g = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int px = base + pl + u * npl;
+                if (px >= W) g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 const int pc = px < W ? px : W - 1;
-                if (arow) {
-                    g.x *= dasr_act_grad_from_out(yq[u].x, act); g.y *= dasr_act_grad_from_out(yq[u].y, act);
-                    g.z *= dasr_act_grad_from_out(yq[u].z, act); g.w *= dasr_act_grad_from_out(yq[u].w, act);
-                }
-                acc[NT].x += g.x; acc[NT].y += g.y; acc[NT].z += g.z; acc[NT].w += g.w;
+                acc[NT].x += g[u].x; acc[NT].y += g[u].y; acc[NT].z += g[u].z; acc[NT].w += g[u].w;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const float d = sRow[(t / (3 * CIN)) * RW + (pc + (t / CIN) % 3) * CIN + t % CIN];
-                    acc[t].x = fmaf(d, g.x, acc[t].x); acc[t].y = fmaf(d, g.y, acc[t].y);
-                    acc[t].z = fmaf(d, g.z, acc[t].z); acc[t].w = fmaf(d, g.w, acc[t].w);
+                    acc[t].x = fmaf(d, g[u].x, acc[t].x); acc[t].y = fmaf(d, g[u].y, acc[t].y);
+                    acc[t].z = fmaf(d, g[u].z, acc[t].z); acc[t].w = fmaf(d, g[u].w, acc[t].w);
                 }
             }
         }
@@ -170,11 +213,22 @@ static int conv_c1_wgrad_impl(const ConvGeom& g, const float* x, const T* dy, co
     DASR_LAUNCH(k_c1_zero, dim3(dasr_cdiv((size_t)(9 * g.Cin + 1) * g.Cout, 256)), dim3(256), 0, stream, dw, 9 * g.Cin * g.Cout,
                 dbias, g.Cout);
     unsigned grid = (unsigned)(g.B * g.H);
-    const unsigned cap = sizeof(T) == 2 ? 768 : 512;   // fp32: two workgroups per CU (more only adds float atomics at the end, measured); bf16: three
+#ifndef C1_WGRAD_WGS_BF16
+#define C1_WGRAD_WGS_BF16 1024
+#endif
+#ifndef C1_WGRAD_WGS_F32
+#define C1_WGRAD_WGS_F32 512
+#endif
+    // fp32: two workgroups per CU (more only adds float atomics at the end, measured); bf16: four (124 VGPRs)
+    const unsigned cap = sizeof(T) == 2 ? C1_WGRAD_WGS_BF16 : C1_WGRAD_WGS_F32;
     if (grid > cap) grid = cap;
     const size_t lds = sizeof(float) * (256 * 4 + 3 * (g.W + 2) * g.Cin);
-    if (g.Cin == 3) DASR_LAUNCH((k_conv3x3_c1_wgrad<T, 3>), dim3(grid), dim3(256), lds, stream, x, dy, yact, dw, dbias, g.B, g.H, g.W, g.Cout, act);
-    else            DASR_LAUNCH((k_conv3x3_c1_wgrad<T, 1>), dim3(grid), dim3(256), lds, stream, x, dy, yact, dw, dbias, g.B, g.H, g.W, g.Cout, act);
+#define C1_WGRAD(CIN, HASY) \
+    DASR_LAUNCH((k_conv3x3_c1_wgrad<T, CIN, HASY>), dim3(grid), dim3(256), lds, stream, x, dy, yact, dw, dbias, g.B, g.H, g.W, g.Cout, act)
+    const bool hasy = yact != nullptr && act != DASR_ACT_NONE;
+    if (g.Cin == 3) { if (hasy) C1_WGRAD(3, true); else C1_WGRAD(3, false); }
+    else            { if (hasy) C1_WGRAD(1, true); else C1_WGRAD(1, false); }
+#undef C1_WGRAD
     DASR_RETURN_LAUNCH_STATUS();
 }
 int conv_c1_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* yact, int act, float* dw, float* dbias,

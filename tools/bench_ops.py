@@ -73,6 +73,18 @@ def main():
         print("dynk_fwd (stp + D)        %8.1f us" % us)
         us = timeit(lambda: ops.dynk_bwd(dD, st, stp, A_w, Wg, Wb, dst), a.iters)
         print("dynk_bwd (dW, dstp, dA+dst: 3 launches) %8.1f us" % us)
+    if not a.only or "c1" in a.only:
+        px = B * H * W
+        depth = torch.randn(B, H, W, 1, device=dev)
+        wm = ops.pack_hwio(torch.randn(3, 3, 1, 128, device=dev) * 0.3)
+        bm = torch.randn(128, device=dev)
+        us = timeit(lambda: ops.conv2d_fwd(depth, wm, bm, act=1), a.iters)
+        print("mask conv 1->128 fwd      %8.1f us  %7.1f GB/s" % (us, px * 128 * 4 / us / 1e3))
+        y = ops.conv2d_fwd(depth, wm, bm, act=1)
+        dy = torch.randn_like(y)
+        us = timeit(lambda: ops.conv2d_wgrad_act(depth, dy, y, (3, 3, 1, 128), 1), a.iters)
+        print("mask conv wgrad           %8.1f us  %7.1f GB/s" % (us, px * 128 * 4 * 2 / us / 1e3))
+        del y, dy
     if not a.only or "conv" in a.only:
         shapes = [(128, 160, 64, 64), (128, 160, 128, 128), (128, 160, 32, 64), (128, 160, 64, 256),
                   (256, 320, 64, 32), (256, 320, 32, 32), (256, 320, 32, 128), (512, 640, 32, 32), (512, 640, 32, 128)]
