@@ -255,6 +255,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: c2 16, c3 32, c4 16, c5 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the forward-only batch-32 roofline pass")
+    ap.add_argument("--serial", action="store_true",
+                    help="profiling aid: depth branch on the main stream (no co-running kernels, so a rocprofv3 kernel trace "
+                         "shows isolated kernel durations); the reported value is then NOT the product configuration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -274,6 +277,11 @@ def main():
         group = dist.group.WORLD
 
     cfg = CONFIGS[args.config]
+    if args.serial:
+        from dasr_amd import graph as _graph_mod
+        _graph_mod.SIDE_STREAM = False
+        print("[bench] --serial: depth branch on the main stream (profiling aid, not the product configuration)",
+              file=sys.stderr, flush=True)
     global LR_H, LR_W, SCALE
     (LR_H, LR_W), SCALE = cfg["lr_hw"], cfg["scale"]
     opt = {"network_G": dict(networks.X8_NETWORK_G, upscale=SCALE), "datasets": {"train": {"depthMaskNum": K_REGIONS}}}

@@ -77,55 +77,96 @@ __global__ void __launch_bounds__(256) k_conv_gather_mfma(GatherArgs a) {
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    for (int kh = 0; kh < a.KH; ++kh)
-        for (int kw = 0; kw < a.KW; ++kw) {
-            int iy, ix;
-            const bool ok = mvalid && gather_src(a, oy, ox, kh, kw, iy, ix);
-            if (!__any(ok)) continue;                       // dead tap for this whole M-tile
-            const float* src = ok ? a.in + (((size_t)b * a.Hi + iy) * a.Wi + ix) * a.Kd : a.in;
-            const int tap = kh * a.KW + kw;
-            // four 8-channel steps per trip: their 4 * (1 + NT) operand loads are issued before the first MFMA (one step
-            // per trip exposed an L2 round trip per 4*NT MFMAs)
-            for (int c0 = 0; c0 < a.Kd; c0 += 32) {
-                float4 A[4], Bf[4][NT];
+    // Which taps land on a source pixel: per lane (okmask) and for any lane of this M-tile (alive, wave-uniform: dead
+    // taps - 3 of 4 of a stride-2 transposed gather - are skipped, not multiplied by zeros).
+    const int T = a.KH * a.KW;                                      // <= 32 (host check)
+    unsigned okmask = 0, alive = 0;
+    for (int tap = 0; tap < T; ++tap) {
+        int iy, ix;
+        const bool ok = mvalid && gather_src(a, oy, ox, tap / a.KW, tap % a.KW, iy, ix);
+        okmask |= ok ? 1u << tap : 0u;
+        alive |= __any(ok) ? 1u << tap : 0u;
+    }
+    // One trip = one tap x 32 channels = four 8-channel steps: 4 * (1 + NT) operand loads, 16 * NT MFMAs.  The trips are
+    // software-pipelined over two statically named operand sets: the loads of trip i+1 are issued (unconditionally, from
+    // clamped addresses - a branch around them makes the compiler wait for them at the join) before the MFMAs of trip i,
+    // so the matrix pipe works while the L2 round trip is in flight (un-pipelined: 31 % of the fp32 MFMA peak).
+    auto load = [&](int tap, int c0, float4 (&A)[4], float4 (&Bf)[4][NT]) {
+        int iy = 0, ix = 0;
+        const bool ok = (okmask >> tap) & 1u;
+        gather_src(a, oy, ox, tap / a.KW, tap % a.KW, iy, ix);
+        const float* src = ok ? a.in + (((size_t)b * a.Hi + iy) * a.Wi + ix) * a.Kd : a.in;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int cc = c0 + 8 * u < a.Kd ? c0 + 8 * u : c0;      // clamped: the extra steps are skipped below
-                    A[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok) A[u] = *(const float4*)(src + cc + 4 * lh);
+        for (int u = 0; u < 4; ++u) {
+            const int cc = c0 + 8 * u < a.Kd ? c0 + 8 * u : c0;      // clamped: the extra steps are skipped in mma()
+            A[u] = *(const float4*)(src + cc + 4 * lh);
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const int nn = n0 + 32 * n + li;
-                        // [tap][n][k] with k contiguous: the transposed half for the forward, the HWIO half for dgrad
-                        Bf[u][n] = *(const float4*)(a.w + ((size_t)tap * a.Nd + nn) * a.Kd + cc + 4 * lh);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (c0 + 8 * u >= a.Kd) break;
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].x, Bf[u][n].x, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].y, Bf[u][n].y, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].z, Bf[u][n].z, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].w, Bf[u][n].w, acc[n], 0, 0, 0);
-                    }
-                }
+            for (int n = 0; n < NT; ++n) {
+                const int nn = n0 + 32 * n + li;
+                // [tap][n][k] with k contiguous: the transposed half for the forward, the HWIO half for dgrad
+                Bf[u][n] = *(const float4*)(a.w + ((size_t)tap * a.Nd + nn) * a.Kd + cc + 4 * lh);
             }
         }
-    // D: column = lane&31 = output channel, rows = pixels of this wave's M-tile
-    const size_t mbase = ((size_t)blockIdx.x * 4 + wv) * 32;
+    };
+    auto mma = [&](int tap, int c0, const float4 (&A)[4], const float4 (&Bf)[4][NT]) {
+        const bool ok = (okmask >> tap) & 1u;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int nn = n0 + 32 * n + li;
-        const float bv = a.bias ? a.bias[nn] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + 8 * u >= a.Kd) break;                          // wave-uniform
+            const float4 av = ok ? A[u] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const size_t mm = mbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            int pb, py, px;
-            if (!gather_pixel(a.B, a.Ho, a.Wo, a.stride, a.gather, mm, pb, py, px)) continue;
+            for (int n = 0; n < NT; ++n) {
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, Bf[u][n].x, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, Bf[u][n].y, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, Bf[u][n].z, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, Bf[u][n].w, acc[n], 0, 0, 0);
+            }
+        }
+    };
+    // next (tap, c0) of the trip sequence; false when the sequence is over (all wave-uniform)
+    auto advance = [&](int& tap, int& c0) {
+        c0 += 32;
+        if (c0 < a.Kd) return true;
+        c0 = 0;
+        for (++tap; tap < T; ++tap)
+            if ((alive >> tap) & 1u) return true;
+        return false;
+    };
+    int tap = 0, c0 = 0;
+    while (tap < T && !((alive >> tap) & 1u)) ++tap;
+    if (tap < T) {
+        float4 A0[4], B0[4][NT], A1[4], B1[4][NT];
+        load(tap, c0, A0, B0);
+        while (true) {
+            int tap1 = tap, c1 = c0;
+            const bool more1 = advance(tap1, c1);
+            load(more1 ? tap1 : tap, more1 ? c1 : c0, A1, B1);
+            mma(tap, c0, A0, B0);
+            if (!more1) break;
+            int tap2 = tap1, c2 = c1;
+            const bool more2 = advance(tap2, c2);
+            load(more2 ? tap2 : tap1, more2 ? c2 : c1, A0, B0);
+            mma(tap1, c1, A1, B1);
+            if (!more2) break;
+            tap = tap2;
+            c0 = c2;
+        }
+    }
+    // D: column = lane&31 = output channel, rows = pixels of this wave's M-tile.  Lane li (either half) decoded pixel
+    // mbase + li at the top of the kernel: its linear output index is fetched from that lane (decoding it again per
+    // accumulator register - divisions and the residue-class walk, 16 * NT times per lane - cost more than the MFMAs of
+    // the small layers).
+    const int mypix = mvalid ? (b * a.Ho + oy) * a.Wo + ox : -1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int pix = __shfl(mypix, (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int nn = n0 + 32 * n + li;
+            const float bv = a.bias ? a.bias[nn] : 0.f;
+            if (pix < 0) continue;
             float v = dasr_act(acc[n][r] + bv, a.act);
-            const size_t o = (((size_t)pb * a.Ho + py) * a.Wo + px) * a.Nd + nn;
+            const size_t o = (size_t)pix * a.Nd + nn;
             if (a.accumulate) v += a.out[o];
             a.out[o] = v;
         }
@@ -166,6 +207,8 @@ __global__ void __launch_bounds__(256) k_conv_gather_wgrad_mfma(GatherWgradArgs 
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     // Eight pixel pairs per trip: all 24 operand loads are issued before the first MFMA (one load -> MFMA per trip made
     // this loop a chain of global-memory latencies: 2.4 ms for a 3 GFLOP layer).  32-bit index arithmetic (M < 2^31).
+    // (Software-pipelining the trips over two operand sets, as in the forward kernel, was measured and is worse here:
+    // 208 VGPRs halve the resident waves and the 6.3 ms it took against 4.5 ms says the waves were hiding more latency.)
     constexpr int GU = 8;
     const unsigned Wm = (unsigned)(a.transposed ? a.W : a.Wo), HWm = (unsigned)(a.transposed ? a.H * a.W : a.Ho * a.Wo);
     for (size_t mb = m0; mb < m1; mb += 2 * GU) {
@@ -213,8 +256,8 @@ __global__ void __launch_bounds__(256) k_conv_gather_wgrad_mfma(GatherWgradArgs 
 }
 
 // ------------------------------------------------------------------------------------------ host side
-bool conv_gather_fwd_supported(const ConvGeom& g) { return (g.Cin % 8) == 0 && (g.Cout % 32) == 0; }
-bool conv_gather_dgrad_supported(const ConvGeom& g) { return (g.Cout % 8) == 0 && (g.Cin % 32) == 0; }
+bool conv_gather_fwd_supported(const ConvGeom& g) { return (g.Cin % 8) == 0 && (g.Cout % 32) == 0 && g.KH * g.KW <= 32; }
+bool conv_gather_dgrad_supported(const ConvGeom& g) { return (g.Cout % 8) == 0 && (g.Cin % 32) == 0 && g.KH * g.KW <= 32; }
 bool conv_gather_wgrad_supported(const ConvGeom& g) { return (g.Cin % 32) == 0 && (g.Cout % 64) == 0; }
 
 static int launch_gather(GatherArgs& a, void* stream) {
