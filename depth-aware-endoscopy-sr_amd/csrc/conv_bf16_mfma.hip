@@ -526,6 +526,34 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_bf16(WgradBf16Args a) 
 #pragma unroll
             for (int t = 0; t < 4; ++t) { bv[t] = b0[t]; bv[4 + t] = b1[t]; }
             const bf16_t* xp = sX + (py * (WB_TW + 2) + px0) * SXP + xoff;
+            if (G == 1) {
+                // All nine taps in this wave: the three taps of a kernel row read 8-pixel windows that start one pixel
+                // apart, so ONE 12-pixel read per kernel row (three transposed reads: pixels 0-3, 4-7, 8-11 of this lane's
+                // half K-step) serves all three - dx = 0: dwords 0..3, dx = 2: dwords 1..4, dx = 1: v_alignbit of neighbours -
+                // instead of two reads per tap.  The A-operand reads were 9 of the 10 KB of LDS traffic per K-step and wave
+                // (1.1 KB per MFMA: over the 128 B/clk of the LDS with four waves issuing one MFMA per 32 clk each).
+                // (Pixels 10, 11 of the last window of a tile row belong to the next row / lie past the tile: read, unused.)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const bf16_t* ap = xp + dy * (WB_TW + 2) * SXP;
+                    const bf16x4 a0 = lds_read_tr16(ap), a1 = lds_read_tr16(ap + 4 * SXP), a2 = lds_read_tr16(ap + 8 * SXP);
+                    unsigned R[6];
+                    __builtin_memcpy(&R[0], &a0, 8);
+                    __builtin_memcpy(&R[2], &a1, 8);
+                    __builtin_memcpy(&R[4], &a2, 8);
+                    unsigned V0[4] = {R[0], R[1], R[2], R[3]}, V2[4] = {R[1], R[2], R[3], R[4]}, V1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) V1[e] = (R[e] >> 16) | (R[e + 1] << 16);
+                    bf16x8 av0, av1, av2;
+                    __builtin_memcpy(&av0, V0, 16);
+                    __builtin_memcpy(&av1, V1, 16);
+                    __builtin_memcpy(&av2, V2, 16);
+                    acc[3 * dy + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0, bv, acc[3 * dy + 0], 0, 0, 0);
+                    acc[3 * dy + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av1, bv, acc[3 * dy + 1], 0, 0, 0);
+                    acc[3 * dy + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av2, bv, acc[3 * dy + 2], 0, 0, 0);
+                }
+                continue;
+            }
 #pragma unroll
             for (int t = 0; t < NACC; ++t) {
                 const int tap = t * G + grp;
