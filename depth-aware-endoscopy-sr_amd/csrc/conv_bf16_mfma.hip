@@ -432,8 +432,8 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_bf16(WgradBf16Args a) 
     constexpr int CIG = 32 * MT, COG = 32 * NTW, NTHR = 256;
     constexpr int TH = wb_th(MT, NTW);
     constexpr int SXP = wb_stride(CIG), SDP = wb_stride(COG);
-    constexpr int G = 4 / (MT * NTW);           // wave groups sharing one (mt, nt) pair, splitting the taps
-    constexpr int NACC = (9 + G - 1) / G;
+    constexpr int G = 4 / (MT * NTW);           // waves sharing one (mt, nt) pair: they split the K-steps (pixels) of a tile
+    constexpr int NACC = 9;                     // every wave holds all nine taps (see the K loop)
     bf16_t* sX = (bf16_t*)smem;                                   // [(TH+2)*(TW+2)][SXP]
     bf16_t* sD = sX + (TH + 2) * (WB_TW + 2) * SXP;               // [TH*TW][SDP]
     // wave-uniform values in SGPRs: the tap split below branches on them around MFMAs, and an MFMA ignores EXEC - a
@@ -518,7 +518,8 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_bf16(WgradBf16Args a) 
         // wave-uniform), as ds_read_b64_tr_b16 requires.
         constexpr int NS = TH * (WB_TW / 16);
 #pragma unroll 2
-        for (int s = 0; s < NS; ++s) {
+        for (int s0 = 0; s0 < NS; s0 += G) {
+            const int s = s0 + grp;
             const int py = s / (WB_TW / 16), px0 = 16 * (s % (WB_TW / 16)) + 8 * lh + tq;
             const bf16_t* dp = sD + (py * WB_TW + px0) * SDP + doff;
             const bf16x4 b0 = lds_read_tr16(dp), b1 = lds_read_tr16(dp + 4 * SDP);
@@ -526,58 +527,66 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_bf16(WgradBf16Args a) 
 #pragma unroll
             for (int t = 0; t < 4; ++t) { bv[t] = b0[t]; bv[4 + t] = b1[t]; }
             const bf16_t* xp = sX + (py * (WB_TW + 2) + px0) * SXP + xoff;
-            if (G == 1) {
-                // All nine taps in this wave: the three taps of a kernel row read 8-pixel windows that start one pixel
-                // apart, so ONE 12-pixel read per kernel row (three transposed reads: pixels 0-3, 4-7, 8-11 of this lane's
-                // half K-step) serves all three - dx = 0: dwords 0..3, dx = 2: dwords 1..4, dx = 1: v_alignbit of neighbours -
-                // instead of two reads per tap.  The A-operand reads were 9 of the 10 KB of LDS traffic per K-step and wave
-                // (1.1 KB per MFMA: over the 128 B/clk of the LDS with four waves issuing one MFMA per 32 clk each).
-                // (Pixels 10, 11 of the last window of a tile row belong to the next row / lie past the tile: read, unused.)
+            // All nine taps in this wave: the three taps of a kernel row read 8-pixel windows that start one pixel
+            // apart, so ONE 12-pixel read per kernel row (three transposed reads: pixels 0-3, 4-7, 8-11 of this lane's
+            // half K-step) serves all three - dx = 0: dwords 0..3, dx = 2: dwords 1..4, dx = 1: v_alignbit of neighbours -
+            // instead of two reads per tap.  The A-operand reads were 9 of the 10 KB of LDS traffic per K-step and wave
+            // (1.1 KB per MFMA: over the 128 B/clk of the LDS with four waves issuing one MFMA per 32 clk each).  Blocks
+            // with fewer than four (mt, nt) pairs used to split the TAPS over their waves, which cannot share reads
+            // (1.8 KB per MFMA, 350 TF on 32->32): they split the K-steps instead and add their accumulators at the end.
+            // (Pixels 10, 11 of the last window of a tile row belong to the next row / lie past the tile: read, unused.)
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const bf16_t* ap = xp + dy * (WB_TW + 2) * SXP;
-                    const bf16x4 a0 = lds_read_tr16(ap), a1 = lds_read_tr16(ap + 4 * SXP), a2 = lds_read_tr16(ap + 8 * SXP);
-                    unsigned R[6];
-                    __builtin_memcpy(&R[0], &a0, 8);
-                    __builtin_memcpy(&R[2], &a1, 8);
-                    __builtin_memcpy(&R[4], &a2, 8);
-                    unsigned V0[4] = {R[0], R[1], R[2], R[3]}, V2[4] = {R[1], R[2], R[3], R[4]}, V1[4];
+            for (int dy = 0; dy < 3; ++dy) {
+                const bf16_t* ap = xp + dy * (WB_TW + 2) * SXP;
+                const bf16x4 a0 = lds_read_tr16(ap), a1 = lds_read_tr16(ap + 4 * SXP), a2 = lds_read_tr16(ap + 8 * SXP);
+                unsigned R[6];
+                __builtin_memcpy(&R[0], &a0, 8);
+                __builtin_memcpy(&R[2], &a1, 8);
+                __builtin_memcpy(&R[4], &a2, 8);
+                unsigned V0[4] = {R[0], R[1], R[2], R[3]}, V2[4] = {R[1], R[2], R[3], R[4]}, V1[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) V1[e] = (R[e] >> 16) | (R[e + 1] << 16);
-                    bf16x8 av0, av1, av2;
-                    __builtin_memcpy(&av0, V0, 16);
-                    __builtin_memcpy(&av1, V1, 16);
-                    __builtin_memcpy(&av2, V2, 16);
-                    acc[3 * dy + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0, bv, acc[3 * dy + 0], 0, 0, 0);
-                    acc[3 * dy + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av1, bv, acc[3 * dy + 1], 0, 0, 0);
-                    acc[3 * dy + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av2, bv, acc[3 * dy + 2], 0, 0, 0);
-                }
-                continue;
+                for (int e = 0; e < 4; ++e) V1[e] = (R[e] >> 16) | (R[e + 1] << 16);
+                bf16x8 av0, av1, av2;
+                __builtin_memcpy(&av0, V0, 16);
+                __builtin_memcpy(&av1, V1, 16);
+                __builtin_memcpy(&av2, V2, 16);
+                acc[3 * dy + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0, bv, acc[3 * dy + 0], 0, 0, 0);
+                acc[3 * dy + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av1, bv, acc[3 * dy + 1], 0, 0, 0);
+                acc[3 * dy + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av2, bv, acc[3 * dy + 2], 0, 0, 0);
             }
+        }
+    }
+    if (G > 1) {
+        // waves grp = 1..G-1 hand their accumulators to wave grp = 0 of the same (mt, nt) pair, one tap at a time through
+        // (G-1) * pairs * 4 KB of the (now idle) staging LDS
+        float* sR = (float*)smem;
 #pragma unroll
-            for (int t = 0; t < NACC; ++t) {
-                const int tap = t * G + grp;
-                if (tap < 9) {
-                    const bf16_t* ap = xp + ((tap / 3) * (WB_TW + 2) + tap % 3) * SXP;
-                    const bf16x4 a0 = lds_read_tr16(ap), a1 = lds_read_tr16(ap + 4 * SXP);
-                    bf16x8 av;
+        for (int t = 0; t < 9; ++t) {
+            __syncthreads();
+            if (grp > 0) {
+                float* q = sR + ((grp - 1) * (MT * NTW) + pair) * 1024 + lane;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { av[e] = a0[e]; av[4 + e] = a1[e]; }
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) q[64 * r] = acc[t][r];
+            }
+            __syncthreads();
+            if (grp == 0) {
+                for (int gg = 0; gg < G - 1; ++gg) {
+                    const float* q = sR + (gg * (MT * NTW) + pair) * 1024 + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += q[64 * r];
                 }
             }
         }
     }
     if (do_bias) a.bslabs[(size_t)blockIdx.y * a.Cout + co0 + tid] = bsum;
     float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
+    if (grp != 0) return;
 #pragma unroll
-    for (int t = 0; t < NACC; ++t) {
-        const int tap = t * G + grp;
-        if (tap >= 9) continue;
+    for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = acc[t][r];
+            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = acc[tap][r];
         }
     }
 }
