@@ -12,3 +12,10 @@ python tools/sean_split.py $O/prof 1 3 $O/sean_split.json > /dev/null; python to
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_c3 -o bench --output-format csv -- python3 bench.py --config c3 --steps 2 --warmup 1 > $O/bench_c3_prof.json 2> $O/bench_c3_prof.err; echo "prof c3 rc=$?"
 python tools/kstats.py $O/prof_c3 45 > $O/kstats_c3.txt
 ls $O
+timeout -k 10 200 python bench.py --config c4 --steps 5 --warmup 2 > $O/bench_c4.json 2> $O/bench_c4.err; echo "bench c4 rc=$?"; cut -c1-160 $O/bench_c4.json
+timeout -k 10 300 python bench.py --config c5 --steps 2 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err; echo "bench c5 rc=$?"; cut -c1-160 $O/bench_c5.json
+timeout -k 10 200 python bench.py --batch 32 --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_b32.json 2> $O/bench_b32.err; echo "bench b32 rc=$?"; cut -c1-160 $O/bench_b32.json
+timeout -k 10 200 python tools/bench_ops.py --batch 16 > $O/ops_b16.txt 2>&1; echo "ops rc=$?"
+timeout -k 10 200 python tools/bench_ops.py --batch 32 --only sean,c1 > $O/ops_b32.txt 2>&1
+timeout -k 10 200 python tools/bench_ops_bf16.py > $O/ops_bf16_c3.txt 2>&1; echo "ops bf16 rc=$?"
+ls $O
