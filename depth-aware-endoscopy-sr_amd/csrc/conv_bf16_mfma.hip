@@ -141,6 +141,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
         auto ldfrag = [&](int j, bf16x8 (&A)[CB_MTW], bf16x8 (&Bf)[NT]) {
             const int tap = j / KS, q = j % KS;
             const int dy = tap / 3, dx = tap - 3 * dy;
+#ifdef DASR_CB_FAKE_SHARE     // timing experiment only (wrong results): what sharing the A reads of a kernel row would buy (measured: nothing - the loop is not bound by LDS read bandwidth)
+            if (dx == 0)
+#endif
 #pragma unroll
             for (int m = 0; m < CB_MTW; ++m)
                 A[m] = *(const bf16x8*)(sIn + ((CB_MTW * wv + m + dy) * CB_HALO_W + li + dx) * CKP + 16 * q + 8 * lh);
@@ -179,8 +182,25 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
     }
 
     // ---- epilogue
+#ifdef DASR_CB_NOEPI              // timing experiment only (wrong results): every accumulator stays live, nothing is stored
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < CB_MTW; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[m][n][r];
+        if (sum == 12345.678f) a.y[blockIdx.x] = dasr_f2bf(sum);
+        return;
+    }
+#endif
     if (TD) {
-        // lane (li = pixel of the tile row, lh): registers 4g .. 4g+3 of acc[m][n] = channels n0 + 32n + 8g + 4lh .. +3
+        // Transposed accumulators (MFMA(B, A)): lane (li = pixel of the tile row, lh), registers 4g .. 4g+3 of acc[m][n] =
+        // channels n0 + 32n + 8g + 4lh .. +3 - four CONSECUTIVE channels of one pixel.  NOT launched: storing straight from
+        // this layout (8 bytes per lane) measured 15-30 % slower than the pixel-major layout's LDS transposition, and a
+        // bounce through LDS from this layout (8-byte writes, 16-byte reads) measured equal to it (fwd 64->64 301 vs 280 us,
+        // dgrad 289 vs 296 us): the epilogue's cost is not its LDS instruction count.
         const bool is_relu = a.act == DASR_ACT_RELU;
         const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
         const bool xin = x0 + li < a.W;
