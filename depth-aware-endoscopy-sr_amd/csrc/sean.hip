@@ -606,9 +606,21 @@ __global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const TA
 //            with a one-hot factor is exact, the accumulation is fp32, so the result is an fp32 sum in a different order;
 //            5x fewer matrix-pipe cycles than the v_mfma_f32_16x16x4_f32 version this replaces (80 of its 300 us).
 // At the end each workgroup writes its dD as a slab; k_sean_dD_reduce sums the slabs in a fixed order.
+// The two phases of consecutive tiles OVERLAP: sG / sR are double / triple buffered, one barrier per tile, and inside an
+// iteration waves 0-3 run [phase 1 of tile i, phase 2 of tile i-1] while waves 4-7 (the second wave of each SIMD) run
+// them in the opposite order - the VALU-heavy elementwise phase of one wave shares its SIMD with the MFMA / LDS phase of
+// the other instead of both waves doing the same thing at the same time (phases back to back: 8.9 us per 64 pixels at
+// fp32, of which each phase is about a third).
+#ifndef SB_STEP_ISSUE
+#define SB_STEP_ISSUE 0      // 1: the next tile's loads of step u right after step u is consumed (measured: no better)
+#endif
 template <typename T> struct SeanBwdCfg;
-template <> struct SeanBwdCfg<bf16_t> { static constexpr int TH = 4, NP = 1; };   // tile rows, bf16 pieces of G
-template <> struct SeanBwdCfg<float>  { static constexpr int TH = 2, NP = 3; };   // three G planes: 2-row tiles (LDS)
+template <> struct SeanBwdCfg<bf16_t> { static constexpr int NP = 1; };   // bf16 pieces of G
+template <> struct SeanBwdCfg<float>  { static constexpr int NP = 3; };   // three exact pieces
+// tile rows: as many as the two G buffers leave room for beside the D table (160 KB of LDS)
+__host__ __device__ constexpr int sean_bwd_lds_bytes(int K, int TH, int NP) {
+    return 4 * (18 * (K + 1) * 64 + 8 * 18 * 16) + 2 * (2 * NP * TH * 32 * 160) + 3 * (((TH + 2) * 34 + 15) / 16 * 16) + 16;
+}
 #define SB16_GST 160           // sG pixel stride in bf16 elements (320 B: the 4 pixel rows of a transposed read fall in
                                // four disjoint 64-byte bank ranges)
 // Eight consecutive region bytes starting at an arbitrary (unaligned) LDS address, as two dwords: three aligned
@@ -638,7 +650,7 @@ __device__ __forceinline__ float4 sean_f4(float4 v) { return v; }
 __device__ __forceinline__ void sean_ldraw(const bf16_t* p, bf16x4& v) { v = *(const bf16x4*)p; }
 __device__ __forceinline__ void sean_ldraw(const float* p, float4& v) { v = *(const float4*)p; }
 
-template <typename T>
+template <typename T, int SB_TH>
 __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     SeanGeom g, const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ t,
     const float* __restrict__ mean, const float* __restrict__ var, const T* __restrict__ gb2,
@@ -649,17 +661,19 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     float* __restrict__ dalpha_b, T* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
     if (flag && *flag != 0) return;
     DASR_DYN_SMEM(smem);
-    constexpr int SB_TH = SeanBwdCfg<T>::TH, NP = SeanBwdCfg<T>::NP;
+    constexpr int NP = SeanBwdCfg<T>::NP;
     constexpr int WPR = 8 / SB_TH, NST = SB_TH;                 // waves per tile row, 4-pixel steps per wave and tile
     constexpr int PLANE = SB_TH * SF_TW * SB16_GST;             // one bf16 plane of G
+    constexpr int NR = (SB_TH + 2) * (SF_TW + 2), NRP = (NR + 15) / 16 * 16;   // region bytes of a tile with halo
     const int K1 = g.K + 1;
     float* sD = (float*)smem;                                   // [18][K+1][64]
-    bf16_t* sG = (bf16_t*)(sD + 18 * K1 * 64);                  // [NP][SB_TH*SF_TW][SB16_GST]: gamma part | beta part
-    float* sred = (float*)(sG + NP * PLANE);                    // [8 waves][18][16] reduction scratch
-    unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);   // [(SB_TH+2)*(SF_TW+2)]
+    bf16_t* sG = (bf16_t*)(sD + 18 * K1 * 64);                  // [2][NP][SB_TH*SF_TW][SB16_GST]: gamma part | beta part
+    float* sred = (float*)(sG + 2 * NP * PLANE);                // [8 waves][18][16] reduction scratch
+    unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);   // [3][NRP]
     const int b = blockIdx.y, c0 = blockIdx.z * 64;
     const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wave id decides the order of the phases and guards MFMAs: keep it in an SGPR (an MFMA ignores EXEC)
+    const int lane = threadIdx.x & 63, wv = DASR_UNIFORM((int)(threadIdx.x >> 6));
     const int cq = lane & 15, ps = lane >> 4;
     const bool live = c0 + 4 * cq < g.C;
     const int c = live ? c0 + 4 * cq : 0;                       // dead lanes shadow channel 0 and never store
@@ -685,26 +699,24 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     const int mydy = wv / 3, mydx = wv % 3;     // tap of this wave (taps 0..7); tap 8 = (2,2) is shared
     const int ly = wv / WPR, lxw = (SF_TW / WPR) * (wv % WPR);   // phase 1: this wave's tile row and first column
     // unconditional loads of the tile's 4-pixel steps (coordinates clamped into the image)
-    auto issue = [&](int tile, SeanBwdLoads<T, NST>& f) {
+    auto issue_step = [&](int tile, int u, SeanBwdLoads<T, NST>& f) {
         const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
         const int y = imin(y0 + ly, g.H - 1);
         const size_t row = ((size_t)b * g.H + y) * g.W;
+        const int x = imin(x0 + lxw + 4 * u + ps, g.W - 1);
+        const size_t p = row + x;
+        sean_ldraw(dout + p * g.C + c, f.g0[u]);
+        sean_ldraw(out + p * g.C + c, f.ov[u]);
+        sean_ldraw(t + p * g.C + c, f.tv[u]);
+        sean_ldraw(gb2 + p * 2 * g.C + c, f.g2[u]);
+        sean_ldraw(gb2 + p * 2 * g.C + g.C + c, f.b2[u]);
+    };
+    auto issue = [&](int tile, SeanBwdLoads<T, NST>& f) {
 #pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int x = imin(x0 + lxw + 4 * u + ps, g.W - 1);
-            const size_t p = row + x;
-            sean_ldraw(dout + p * g.C + c, f.g0[u]);
-            sean_ldraw(out + p * g.C + c, f.ov[u]);
-            sean_ldraw(t + p * g.C + c, f.tv[u]);
-            sean_ldraw(gb2 + p * 2 * g.C + c, f.g2[u]);
-            sean_ldraw(gb2 + p * 2 * g.C + g.C + c, f.b2[u]);
-        }
+        for (int u = 0; u < NST; ++u) issue_step(tile, u, f);
     };
     auto f4 = [](auto v) { return sean_f4(v); };
-    // the tile's region bytes (with halo; K = "no region" outside the image) travel with the prefetch too: one byte per
-    // thread, loaded a tile ahead - staged after the barrier they cost a full global-load latency per tile (one
-    // workgroup per CU: nothing else to hide it)
-    constexpr int NR = (SB_TH + 2) * (SF_TW + 2);                 // <= 204 bytes
+    // the region bytes of a tile with halo (K = "no region" outside the image): one byte per thread of waves 0-3
     auto issue_r = [&](int tile) {
         const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
         const int i = (int)threadIdx.x < NR ? (int)threadIdx.x : 0;
@@ -713,97 +725,90 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
         if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = region[((size_t)b * g.H + gy) * g.W + gx];
         return v;
     };
-    SeanBwdLoads<T, NST> cur;
-    unsigned char rcur = (unsigned char)g.K;
-    if ((int)blockIdx.x < ntiles) { issue(blockIdx.x, cur); rcur = issue_r(blockIdx.x); }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- phase 1 of one tile: per-pixel work, G -> sGb; region bytes of the tile in sRb
+    // (the registers of step u are free once it is consumed: the NEXT tile's loads of that step are issued right there)
+    auto phase1 = [&](int tile, int next_tile, SeanBwdLoads<T, NST>& cur, bf16_t* sGb, const unsigned char* sRb) {
         const int x0 = (tile % tiles_x) * SF_TW, y0 = (tile / tiles_x) * SB_TH;
-        __syncthreads();                          // previous phase 2 is done with sG / sR
-        if ((int)threadIdx.x < NR) sR[threadIdx.x] = rcur;
-        __syncthreads();
-        // ---- phase 1
-        {
-            const int y = y0 + ly;
+        const int y = y0 + ly;
 #pragma unroll
-            for (int u = 0; u < NST; ++u) {
-                const int lx = lxw + 4 * u + ps, x = x0 + lx;
-                float4 G1 = zero4, B1 = zero4;
-                if (live && y < g.H && x < g.W) {
-                    const size_t p = ((size_t)b * g.H + y) * g.W + x;
-                    float4 g0 = f4(cur.g0[u]);
-                    if (relu) {
-                        const float4 ov = f4(cur.ov[u]);
-                        g0.x = ov.x > 0.f ? g0.x : 0.f; g0.y = ov.y > 0.f ? g0.y : 0.f;
-                        g0.z = ov.z > 0.f ? g0.z : 0.f; g0.w = ov.w > 0.f ? g0.w : 0.f;
-                    }
-                    if (dres) st4(dres + p * g.C + c, g0);
-                    const float4 tv = f4(cur.tv[u]), g2 = f4(cur.g2[u]), b2 = f4(cur.b2[u]);
-                    float4 g1, b1;
-                    sean_gather(sD, sR, K1, ly, lx, cq, bg, bb, g1, b1);
-                    const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
-                    const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
-                    const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
-                    st4(dgb2 + p * 2 * g.C + c, make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y,
-                                                            (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w));
-                    st4(dgb2 + p * 2 * g.C + g.C + c, make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y,
-                                                                  (1.f - a_b) * g0.z, (1.f - a_b) * g0.w));
-                    dag += dgam.x * (g1.x - g2.x) + dgam.y * (g1.y - g2.y) + dgam.z * (g1.z - g2.z) +
-                           dgam.w * (g1.w - g2.w);
-                    dab += g0.x * (b1.x - b2.x) + g0.y * (b1.y - b2.y) + g0.z * (b1.z - b2.z) + g0.w * (b1.w - b2.w);
-                    G1 = make_float4(a_g * dgam.x, a_g * dgam.y, a_g * dgam.z, a_g * dgam.w);
-                    B1 = make_float4(a_b * g0.x, a_b * g0.y, a_b * g0.z, a_b * g0.w);
-                    dbg = f4add(dbg, G1);
-                    dbb = f4add(dbb, B1);
-                    float4 dxh;
-                    dxh.x = g0.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x);
-                    dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
-                    dxh.z = g0.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z);
-                    dxh.w = g0.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w);
-                    st4(dt + p * g.C + c, dxh);
-                    S1 = f4add(S1, dxh);
-                    S2.x = fmaf(dxh.x, xc.x, S2.x); S2.y = fmaf(dxh.y, xc.y, S2.y);
-                    S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
+        for (int u = 0; u < NST; ++u) {
+            const int lx = lxw + 4 * u + ps, x = x0 + lx;
+            float4 G1 = zero4, B1 = zero4;
+            if (live && y < g.H && x < g.W) {
+                const size_t p = ((size_t)b * g.H + y) * g.W + x;
+                float4 g0 = f4(cur.g0[u]);
+                if (relu) {
+                    const float4 ov = f4(cur.ov[u]);
+                    g0.x = ov.x > 0.f ? g0.x : 0.f; g0.y = ov.y > 0.f ? g0.y : 0.f;
+                    g0.z = ov.z > 0.f ? g0.z : 0.f; g0.w = ov.w > 0.f ? g0.w : 0.f;
                 }
-                bf16_t* gp = sG + (ly * SF_TW + lx) * SB16_GST + 4 * cq;
-#pragma unroll
-                for (int pc = 0; pc < NP; ++pc) {  // bf16 pieces of G: value, then the exact residuals (fp32 activations)
-                    st4(gp + pc * PLANE, G1);      // channels 0..63: gamma part
-                    st4(gp + pc * PLANE + 64, B1); // channels 64..127: beta part
-                    if (pc + 1 < NP) {
-                        G1 = make_float4(G1.x - round_to<bf16_t>(G1.x), G1.y - round_to<bf16_t>(G1.y),
-                                         G1.z - round_to<bf16_t>(G1.z), G1.w - round_to<bf16_t>(G1.w));
-                        B1 = make_float4(B1.x - round_to<bf16_t>(B1.x), B1.y - round_to<bf16_t>(B1.y),
-                                         B1.z - round_to<bf16_t>(B1.z), B1.w - round_to<bf16_t>(B1.w));
-                    }
-                }
-                DASR_SCHED_BARRIER();              // one step's gather rows at a time (256-VGPR budget)
+                if (dres) st4(dres + p * g.C + c, g0);
+                const float4 tv = f4(cur.tv[u]), g2 = f4(cur.g2[u]), b2 = f4(cur.b2[u]);
+                float4 g1, b1;
+                sean_gather(sD, sRb, K1, ly, lx, cq, bg, bb, g1, b1);
+                const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
+                const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
+                const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
+                st4(dgb2 + p * 2 * g.C + c, make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y,
+                                                        (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w));
+                st4(dgb2 + p * 2 * g.C + g.C + c, make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y,
+                                                              (1.f - a_b) * g0.z, (1.f - a_b) * g0.w));
+                dag += dgam.x * (g1.x - g2.x) + dgam.y * (g1.y - g2.y) + dgam.z * (g1.z - g2.z) +
+                       dgam.w * (g1.w - g2.w);
+                dab += g0.x * (b1.x - b2.x) + g0.y * (b1.y - b2.y) + g0.z * (b1.z - b2.z) + g0.w * (b1.w - b2.w);
+                G1 = make_float4(a_g * dgam.x, a_g * dgam.y, a_g * dgam.z, a_g * dgam.w);
+                B1 = make_float4(a_b * g0.x, a_b * g0.y, a_b * g0.z, a_b * g0.w);
+                dbg = f4add(dbg, G1);
+                dbb = f4add(dbb, B1);
+                float4 dxh;
+                dxh.x = g0.x * (1.f + a_g * g1.x + (1.f - a_g) * g2.x);
+                dxh.y = g0.y * (1.f + a_g * g1.y + (1.f - a_g) * g2.y);
+                dxh.z = g0.z * (1.f + a_g * g1.z + (1.f - a_g) * g2.z);
+                dxh.w = g0.w * (1.f + a_g * g1.w + (1.f - a_g) * g2.w);
+                st4(dt + p * g.C + c, dxh);
+                S1 = f4add(S1, dxh);
+                S2.x = fmaf(dxh.x, xc.x, S2.x); S2.y = fmaf(dxh.y, xc.y, S2.y);
+                S2.z = fmaf(dxh.z, xc.z, S2.z); S2.w = fmaf(dxh.w, xc.w, S2.w);
             }
-        }
-        if (tile + (int)gridDim.x < ntiles) {     // in flight during the matrix phase
-            issue(tile + gridDim.x, cur);
-            rcur = issue_r(tile + gridDim.x);
-        }
-        __syncthreads();
-        // ---- phase 2: one-hot(region) x G, 32 pixels per MFMA (one tile row per K step)
-        {
-            const int i16 = lane & 15, kg = lane >> 4;            // A: region row i16, pixels 8*kg .. 8*kg+7 of the step
-            const int tq = (lane & 15) >> 2, tp = lane & 3;       // transposed-read role inside the 16-lane group
+#if SB_STEP_ISSUE
+            issue_step(next_tile, u, cur);
+#endif
+            bf16_t* gp = sGb + (ly * SF_TW + lx) * SB16_GST + 4 * cq;
 #pragma unroll
-            for (int s = 0; s < SB_TH; ++s) {
-                unsigned my_lo, my_hi, t8_lo, t8_hi;
-                lds_ld8_unaligned(sR + (s + mydy) * (SF_TW + 2) + 8 * kg + mydx, my_lo, my_hi);
-                lds_ld8_unaligned(sR + (s + 2) * (SF_TW + 2) + 8 * kg + 2, t8_lo, t8_hi);
-                bf16x8 a_my, a_8;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    a_my[j] = dasr_f2bf((int)((my_lo >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
-                    a_my[4 + j] = dasr_f2bf((int)((my_hi >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
-                    a_8[j] = dasr_f2bf((int)((t8_lo >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
-                    a_8[4 + j] = dasr_f2bf((int)((t8_hi >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
+            for (int pc = 0; pc < NP; ++pc) {  // bf16 pieces of G: value, then the exact residuals (fp32 activations)
+                st4(gp + pc * PLANE, G1);      // channels 0..63: gamma part
+                st4(gp + pc * PLANE + 64, B1); // channels 64..127: beta part
+                if (pc + 1 < NP) {
+                    G1 = make_float4(G1.x - round_to<bf16_t>(G1.x), G1.y - round_to<bf16_t>(G1.y),
+                                     G1.z - round_to<bf16_t>(G1.z), G1.w - round_to<bf16_t>(G1.w));
+                    B1 = make_float4(B1.x - round_to<bf16_t>(B1.x), B1.y - round_to<bf16_t>(B1.y),
+                                     B1.z - round_to<bf16_t>(B1.z), B1.w - round_to<bf16_t>(B1.w));
                 }
-                const bf16_t* gq0 = sG + (s * SF_TW + 8 * kg + tq) * SB16_GST + 4 * tp;
+            }
+            DASR_SCHED_BARRIER();              // one step's gather rows at a time (256-VGPR budget)
+        }
+    };
+    // ---- phase 2 of one tile: one-hot(region) x G, 32 pixels per MFMA (one tile row per K step).  Called under
+    // wave-uniform conditions only (EXEC all ones: ds_read_b64_tr_b16 and the MFMAs need it).
+    auto phase2 = [&](const bf16_t* sGb, const unsigned char* sRb) {
+        const int i16 = lane & 15, kg = lane >> 4;            // A: region row i16, pixels 8*kg .. 8*kg+7 of the step
+        const int tq = (lane & 15) >> 2, tp = lane & 3;       // transposed-read role inside the 16-lane group
 #pragma unroll
-                for (int pc = 0; pc < NP; ++pc) {
+        for (int s = 0; s < SB_TH; ++s) {
+            unsigned my_lo, my_hi, t8_lo, t8_hi;
+            lds_ld8_unaligned(sRb + (s + mydy) * (SF_TW + 2) + 8 * kg + mydx, my_lo, my_hi);
+            lds_ld8_unaligned(sRb + (s + 2) * (SF_TW + 2) + 8 * kg + 2, t8_lo, t8_hi);
+            bf16x8 a_my, a_8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a_my[j] = dasr_f2bf((int)((my_lo >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
+                a_my[4 + j] = dasr_f2bf((int)((my_hi >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
+                a_8[j] = dasr_f2bf((int)((t8_lo >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
+                a_8[4 + j] = dasr_f2bf((int)((t8_hi >> (8 * j)) & 0xffu) == i16 ? 1.f : 0.f);
+            }
+            const bf16_t* gq0 = sGb + (s * SF_TW + 8 * kg + tq) * SB16_GST + 4 * tp;
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
                 const bf16_t* gq = gq0 + pc * PLANE;
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
@@ -824,6 +829,50 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
                     for (int e = 0; e < 4; ++e) { bv[e] = lo[e]; bv[4 + e] = hi[e]; }
                     acc[8] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_8, bv, acc[8], 0, 0, 0);
                 }
+            }
+        }
+    };
+    // This workgroup's tiles: blockIdx.x + i * gridDim.x, i = 0 .. n-1.  Iteration i (0 .. n): phase 1 of tile i into
+    // buffer i & 1 and phase 2 of tile i-1 from buffer (i-1) & 1, in the order the wave's half dictates; the region bytes
+    // of tile i+1 are written to sR[(i+1) % 3] (waves 0-3 only: their loads and the wait on them stay out of the other
+    // waves' instruction stream) and become visible at the next barrier.
+    const int n = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    auto tile_of = [&](int i) { return (int)blockIdx.x + (i < n ? i : n - 1) * (int)gridDim.x; };   // clamped
+    // Order of the two phases inside an iteration.  fp32 (three G planes: the matrix phase is as long as the elementwise
+    // one): waves 4-7 - the second wave of each SIMD - run phase 2 first, so the VALU phase of one wave shares the SIMD with
+    // the MFMA / LDS phase of the other (253 -> 237 us).  bf16 (one plane, latency-bound): the same order everywhere, so
+    // that every wave issues its next loads as early as possible (flipped: 1075-1090 us, not flipped 972).
+#ifndef SB_FLIP_MODE
+#define SB_FLIP_MODE (sizeof(T) == 2 ? 2 : 0)
+#endif
+    const bool second_half = SB_FLIP_MODE == 0 ? wv >= 4 : SB_FLIP_MODE == 1 ? (wv & 1) != 0 : false;
+    const bool stager = SB_FLIP_MODE == 0 ? wv < 4 : true;
+    SeanBwdLoads<T, NST> cur;
+    unsigned char rnext = (unsigned char)g.K;
+    if (n > 0) {
+        issue(tile_of(0), cur);
+        if (stager) {
+            rnext = issue_r(tile_of(0));
+            if ((int)threadIdx.x < NR) sR[threadIdx.x] = rnext;
+            rnext = issue_r(tile_of(1));
+        }
+        for (int i = 0; i <= n; ++i) {
+            __syncthreads();
+            if (stager) {
+                if ((int)threadIdx.x < NR) sR[((i + 1) % 3) * NRP + threadIdx.x] = rnext;
+                rnext = issue_r(tile_of(i + 2));
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if ((h == 0) != second_half) {
+                    if (i < n) {
+                        phase1(tile_of(i), tile_of(i + 1), cur, sG + (i & 1) * NP * PLANE, sR + (i % 3) * NRP);
+#if !SB_STEP_ISSUE
+                        issue(tile_of(i + 1), cur);      // in flight during the other phase and the barrier
+#endif
+                    }
+                } else if (i >= 1) {
+                    phase2(sG + ((i - 1) & 1) * NP * PLANE, sR + ((i - 1) % 3) * NRP);
                 }
             }
         }
@@ -1028,13 +1077,25 @@ static int sean_bwd_impl(const T* dout, const T* out, const T* t, const float* m
     }
     if (fast) {
         int nblk = sean_bwd_blocks_per_sample(B, H, W);
-        constexpr int TH = SeanBwdCfg<T>::TH, NP = SeanBwdCfg<T>::NP;
+        constexpr int NP = SeanBwdCfg<T>::NP;
+        // tile rows (bf16 / fp32 with its three G planes): as many as the two G buffers leave room for beside the D table
+#ifndef SB_TH_BF16
+#define SB_TH_BF16 2
+#endif
+        constexpr int TH_BIG = sizeof(T) == 2 ? SB_TH_BF16 : 1, TH_SMALL = sizeof(T) == 2 ? 2 : 1;
+        const bool big = sean_bwd_lds_bytes(K, TH_BIG, NP) <= 160 * 1024;
+        const int TH = big ? TH_BIG : TH_SMALL;
         int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + TH - 1) / TH);
-        size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64 + 8 * 18 * 16) +
-                     sizeof(bf16_t) * (size_t)(NP * TH * SF_TW * SB16_GST) + (TH + 2) * (SF_TW + 2) + 8;
-        DASR_LAUNCH((k_sean_bwd_a_onehot<T>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
-                    mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
-                    dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
+        size_t lds = (size_t)sean_bwd_lds_bytes(K, TH, NP);
+        if (lds > 160 * 1024) return DASR_E_UNSUPPORTED;
+        if (big)
+            DASR_LAUNCH((k_sean_bwd_a_onehot<T, TH_BIG>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
+                        mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
+                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
+        else
+            DASR_LAUNCH((k_sean_bwd_a_onehot<T, TH_SMALL>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
+                        mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
+                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
         size_t n = (size_t)B * 18 * K * C;
         DASR_LAUNCH(k_sean_dD_reduce, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, (const float*)slabs, onehot_flag, dD,
                     18 * K * C, nblk, n);
