@@ -611,6 +611,10 @@ __global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const TA
 // them in the opposite order - the VALU-heavy elementwise phase of one wave shares its SIMD with the MFMA / LDS phase of
 // the other instead of both waves doing the same thing at the same time (phases back to back: 8.9 us per 64 pixels at
 // fp32, of which each phase is about a third).
+#ifndef SB_DEEP_PREFETCH
+#define SB_DEEP_PREFETCH 0      // 1: bf16 loads two tiles ahead over two register sets (measured: no change - the kernel is
+                                // instruction-bound, not bound by bytes in flight)
+#endif
 #ifndef SB_STEP_ISSUE
 #define SB_STEP_ISSUE 0      // 1: the next tile's loads of step u right after step u is consumed (measured: no better)
 #endif
@@ -847,16 +851,22 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
 #endif
     const bool second_half = SB_FLIP_MODE == 0 ? wv >= 4 : SB_FLIP_MODE == 1 ? (wv & 1) != 0 : false;
     const bool stager = SB_FLIP_MODE == 0 ? wv < 4 : true;
-    SeanBwdLoads<T, NST> cur;
+    // Operand prefetch distance: bf16 keeps TWO register sets (20 VGPRs each at two rows per tile) and loads two tiles
+    // ahead - the kernel is latency-bound there (bytes in flight per CU / round-trip time); fp32 has no registers left
+    // for a second set (242 of 256).  The tile loop is unrolled by two so that the sets have static names.
+    constexpr bool DEEP = sizeof(T) == 2 && SB_DEEP_PREFETCH;
+    constexpr int DIST = DEEP ? 2 : 1;
+    SeanBwdLoads<T, NST> setA, setB;
     unsigned char rnext = (unsigned char)g.K;
     if (n > 0) {
-        issue(tile_of(0), cur);
+        issue(tile_of(0), setA);
+        if (DEEP) issue(tile_of(1), setB);
         if (stager) {
             rnext = issue_r(tile_of(0));
             if ((int)threadIdx.x < NR) sR[threadIdx.x] = rnext;
             rnext = issue_r(tile_of(1));
         }
-        for (int i = 0; i <= n; ++i) {
+        auto iteration = [&](int i, SeanBwdLoads<T, NST>& cur) {
             __syncthreads();
             if (stager) {
                 if ((int)threadIdx.x < NR) sR[((i + 1) % 3) * NRP + threadIdx.x] = rnext;
@@ -866,15 +876,19 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             for (int h = 0; h < 2; ++h) {
                 if ((h == 0) != second_half) {
                     if (i < n) {
-                        phase1(tile_of(i), tile_of(i + 1), cur, sG + (i & 1) * NP * PLANE, sR + (i % 3) * NRP);
+                        phase1(tile_of(i), tile_of(i + DIST), cur, sG + (i & 1) * NP * PLANE, sR + (i % 3) * NRP);
 #if !SB_STEP_ISSUE
-                        issue(tile_of(i + 1), cur);      // in flight during the other phase and the barrier
+                        issue(tile_of(i + DIST), cur);   // in flight during the other phase, the barrier (and, bf16, a whole tile)
 #endif
                     }
                 } else if (i >= 1) {
                     phase2(sG + ((i - 1) & 1) * NP * PLANE, sR + ((i - 1) % 3) * NRP);
                 }
             }
+        };
+        for (int i = 0; i <= n; i += 2) {
+            iteration(i, setA);
+            if (i + 1 <= n) iteration(i + 1, DEEP ? setB : setA);
         }
     }
     // ---- per-channel sums: reduce over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
