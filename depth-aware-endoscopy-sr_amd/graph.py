@@ -31,6 +31,7 @@ import os as _os
 import threading as _threading
 TAIL_WGRAD_SIDE = False  # weight gradients of the HR tail on the (then idle) depth-branch stream; see conv(side_wgrad=)
 FUSE_INSTNORM_STATS = False  # measured: 115.5 -> 111.5 frames/s when on (two more barriers + reductions in the 64->64 conv epilogue cost more than the statistics pass they replace); the entry point stays, tested
+ENCODER_S2D = True     # bf16 path: encoder layers 2-5 on the bf16 stride-1 kernels (space-to-depth form); False: fp32 gather kernels
 WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
 _SIDE_LOCK = _threading.Lock()
@@ -255,6 +256,89 @@ def to_bf16(tape, x):
 
     tape.record(bwd)
     return out
+
+
+def to_f32(tape, x):
+    """bf16 -> fp32 (the encoder's last feature map feeds the fp32 region pooling); the gradient comes back rounded."""
+    x.uses += 1
+    out = Var(ops.cast_to_f32(x.data), x.requires_grad)
+
+    def bwd():
+        if out.grad is None:
+            return
+        g = out.grad
+        out.grad = None
+        if x.requires_grad:
+            accum(x, ops.cast_to_bf16(g))
+
+    tape.record(bwd)
+    return out
+
+
+def space_to_depth2(tape, x):
+    """x -> bf16 space-to-depth image (ops.space_to_depth2); x fp32 or bf16."""
+    x.uses += 1
+    out = Var(ops.space_to_depth2(x.data), x.requires_grad)
+
+    def bwd():
+        if out.grad is None:
+            return
+        g = out.grad
+        out.grad = None
+        if x.requires_grad:
+            if x.grad is None:
+                x.grad = ops.depth_to_space2_bwd(g, x.data.shape, x.data.dtype)
+            else:
+                ops.depth_to_space2_bwd(g, x.data.shape, x.data.dtype, out=x.grad)
+
+    tape.record(bwd)
+    return out
+
+
+def expand_s2(tape, wp):
+    """fp32 packed kernel of a 3x3 stride-2 conv -> bf16 packed kernel of its stride-1 form on the space-to-depth image."""
+    _, _, _, Cin, Cout = wp.data.shape
+    out = Var(ops.weight_expand_s2(wp.data), wp.requires_grad)
+
+    def bwd():
+        if out.grad is None:
+            return
+        if out.grad_event is not None:
+            torch.cuda.current_stream().wait_event(out.grad_event)
+            out.grad.record_stream(torch.cuda.current_stream())
+        g = out.grad
+        out.grad = None
+        accum(wp, ops.weight_collapse_s2(g, Cin, Cout))
+
+    tape.record(bwd)
+    return out
+
+
+def expand_t2(tape, wp, bias):
+    """fp32 packed kernel + bias of a 3x3 stride-2 ConvTranspose2d -> (bf16 packed kernel, bias) of the stride-1 convolution
+    Cin -> 4 Cout whose PixelShuffle(2) it is."""
+    _, _, _, Cin, Cout = wp.data.shape
+    w4, b4 = ops.weight_expand_t2(wp.data, bias.data if bias is not None else None)
+    wout = Var(w4, wp.requires_grad)
+    bout = Var(b4, bias.requires_grad) if bias is not None else None
+
+    def bwd():
+        if wout.grad is None:
+            return
+        for v in (wout, bout):
+            if v is not None and v.grad_event is not None:
+                torch.cuda.current_stream().wait_event(v.grad_event)
+        gw, gb = wout.grad, (bout.grad if bout is not None else None)
+        wout.grad = None
+        if bout is not None:
+            bout.grad = None
+        dw, db = ops.weight_collapse_t2(gw, gb, Cin, Cout)
+        accum(wp, dw)
+        if bias is not None and db is not None:
+            accum(bias, db)
+
+    tape.record(bwd)
+    return wout, bout
 
 
 def add(tape, a, b):
@@ -516,7 +600,21 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=No
     # Encoder.forward (sftmd_arch.py:771-783)
     e1 = conv(tape, x0, _wn(tape, P, "encoder.layer1"), P["encoder.layer1.bias"], act=L)
     st = None
-    if len(cfg["which_ResBlk_depth"]) > 0:
+    # (the bf16 kernels want channel counts in multiples of 32: true for the reference's 32/64/128/L = 256 or 32 plan)
+    s2d_ok = all(P["encoder.layer%d.weight_v" % i].data.shape[0] % 32 == 0 and
+                 P["encoder.layer%d.weight_v" % i].data.shape[1] % 32 == 0 for i in (2, 3, 4, 5))
+    if len(cfg["which_ResBlk_depth"]) > 0 and tape.act_dtype == torch.bfloat16 and ENCODER_S2D and s2d_ok:
+        # mixed precision: the stride-2 layers as stride-1 bf16-MFMA convolutions of space-to-depth images / with a
+        # PixelShuffle(2) epilogue (csrc/s2d.hip); fp32 master weights, weight norm and its gradient as everywhere
+        def s2(name, x, act):
+            return conv(tape, space_to_depth2(tape, x), expand_s2(tape, _wn(tape, P, name)), P[name + ".bias"], act=act)
+        e2 = s2("encoder.layer2", e1, L)
+        e3 = s2("encoder.layer3", e2, L)
+        w4, b4 = expand_t2(tape, _wn(tape, P, "encoder.layer4", True), P["encoder.layer4.bias"])
+        e4 = conv(tape, e3, w4, b4, act=L, ps_r=2)
+        e5 = to_f32(tape, s2("encoder.layer5", e4, ops.ACT_NONE))
+        st = region_pool(tape, e5, depth_mask)
+    elif len(cfg["which_ResBlk_depth"]) > 0:
         e2 = conv(tape, e1, _wn(tape, P, "encoder.layer2"), P["encoder.layer2.bias"], stride=2, act=L)
         e3 = conv(tape, e2, _wn(tape, P, "encoder.layer3"), P["encoder.layer3.bias"], stride=2, act=L)
         e4 = conv(tape, e3, _wn(tape, P, "encoder.layer4", True), P["encoder.layer4.bias"], stride=2,

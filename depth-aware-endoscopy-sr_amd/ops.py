@@ -134,6 +134,58 @@ def cast_to_f32(x):
     return out
 
 
+# ---- the encoder's stride-2 layers in stride-1 form (csrc/s2d.hip; bf16 path only) ----------------------------------
+def space_to_depth2(x):
+    """[B,H,W,C] fp32 or bf16 -> bf16 [B,ceil(H/2),ceil(W/2),4C], channel (2py+px)C + c = x[2i+py][2j+px][c]."""
+    B, H, W, C = x.shape
+    out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), dtype=BF16, device=x.device)
+    _call("dasr_space_to_depth2_bf16", _pa(x), 1 if x.dtype == BF16 else 0, _pa(out), B, H, W, C)
+    return out
+
+
+def depth_to_space2_bwd(dy, x_shape, dtype, out=None):
+    """Adjoint of space_to_depth2: bf16 gradient [B,Hs,Ws,4C] -> gradient of x (``dtype``); ``out``: accumulate into it."""
+    B, H, W, C = x_shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty(tuple(x_shape), dtype=dtype, device=dy.device)
+    _call("dasr_depth_to_space2_bwd_bf16", _pa(dy), _pa(out), 1 if out.dtype == BF16 else 0, 1 if acc else 0, B, H, W, C)
+    return out
+
+
+def weight_expand_s2(w_packed):
+    """fp32 packed kernel (2,3,3,Cin,Cout) of a stride-2 conv -> bf16 packed kernel (2,3,3,4Cin,Cout) of its stride-1 form."""
+    _, KH, KW, Cin, Cout = w_packed.shape
+    assert (KH, KW) == (3, 3)
+    out = torch.empty((2, 3, 3, 4 * Cin, Cout), dtype=BF16, device=w_packed.device)
+    _call("dasr_weight_expand_s2_bf16", _p(w_packed), _pa(out), Cin, Cout)
+    return out
+
+
+def weight_collapse_s2(dw_expanded, Cin, Cout):
+    out = torch.empty((3, 3, Cin, Cout), dtype=torch.float32, device=dw_expanded.device)
+    _call("dasr_weight_collapse_s2", _p(dw_expanded), _p(out), Cin, Cout)
+    return out
+
+
+def weight_expand_t2(w_packed, bias):
+    """fp32 packed kernel (2,3,3,Cin,Cout) of a stride-2 ConvTranspose2d (+ bias) -> bf16 packed kernel (2,3,3,Cin,4Cout) and
+    bias [4Cout] of the stride-1 convolution whose PixelShuffle(2) is the transposed convolution."""
+    _, KH, KW, Cin, Cout = w_packed.shape
+    assert (KH, KW) == (3, 3)
+    out = torch.empty((2, 3, 3, Cin, 4 * Cout), dtype=BF16, device=w_packed.device)
+    b4 = torch.empty((4 * Cout,), dtype=torch.float32, device=w_packed.device) if bias is not None else None
+    _call("dasr_weight_expand_t2_bf16", _p(w_packed), _p(bias, True), _pa(out), _p(b4, True), Cin, Cout)
+    return out, b4
+
+
+def weight_collapse_t2(dw_expanded, db_expanded, Cin, Cout):
+    dw = torch.empty((3, 3, Cin, Cout), dtype=torch.float32, device=dw_expanded.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=dw_expanded.device) if db_expanded is not None else None
+    _call("dasr_weight_collapse_t2", _p(dw_expanded), _p(db_expanded, True), _p(dw), _p(db, True), Cin, Cout)
+    return dw, db
+
+
 def zeros(shape, like):
     return torch.zeros(shape, dtype=torch.float32, device=like.device)
 

@@ -306,6 +306,27 @@ int dasr_accumulate_bf16(unsigned short* dst, const unsigned short* src, size_t 
 int dasr_cast_f32_to_bf16(const float* src, unsigned short* dst, size_t n, void* stream);
 int dasr_cast_bf16_to_f32(const unsigned short* src, float* dst, int accumulate, size_t n, void* stream);
 
+/* ---- the encoder's stride-2 layers on the bf16 stride-1 kernels (csrc/s2d.hip) -----------------------------------
+ * Encoder (sftmd_arch.py:745-749, 771-783): nn.Conv2d(.., 3, stride=2, padding=1) x3 and
+ * nn.ConvTranspose2d(.., 3, stride=2, padding=1, output_padding=1).  With bf16 activations they are expressed as
+ * stride-1 3x3 convolutions (dasr_conv2d_*_bf16) of a space-to-depth image / with a PixelShuffle(2) epilogue:
+ *   space_to_depth2:        y[b][i][j][(2py+px)C + c] = x[b][2i+py][2j+px][c], zero beyond an odd edge; x fp32 or bf16
+ *   depth_to_space2_bwd:    the adjoint (gradient of the above), into an fp32 or bf16 tensor, optionally accumulating
+ *   weight_expand_s2:       fp32 HWIO [3][3][Cin][Cout] -> the bf16 packed kernel [2][3][3][4Cin][Cout] of the stride-1 form
+ *   weight_collapse_s2:     fp32 gradient of the expanded kernel [3][3][4Cin][Cout] -> [3][3][Cin][Cout]
+ *   weight_expand_t2 / weight_collapse_t2: the same for the transposed convolution: [3][3][Cin][Cout] <-> Cin -> 4 Cout
+ *                           (output channel 4co + 2a + b = phase (a, b) of the PixelShuffle), bias repeated / summed.
+ * All C % 4 == 0. */
+int dasr_space_to_depth2_bf16(const void* x, int x_is_bf16, unsigned short* y, int B, int H, int W, int C, void* stream);
+int dasr_depth_to_space2_bwd_bf16(const unsigned short* dy, void* dx, int dx_is_bf16, int accumulate, int B, int H, int W,
+                                  int C, void* stream);
+int dasr_weight_expand_s2_bf16(const float* w_hwio, unsigned short* out, int Cin, int Cout, void* stream);
+int dasr_weight_collapse_s2(const float* dw_expanded, float* dw_hwio, int Cin, int Cout, void* stream);
+int dasr_weight_expand_t2_bf16(const float* w_hwio, const float* bias, unsigned short* out, float* bias_out, int Cin,
+                               int Cout, void* stream);
+int dasr_weight_collapse_t2(const float* dw_expanded, const float* dbias_expanded, float* dw_hwio, float* dbias, int Cin,
+                            int Cout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1146,6 +1146,68 @@ def check_bf16_conv_variants(device, seed=0):
     return {"%d->%d ps%d H%d" % k: tuple(round(v, 7) for v in vs) for k, vs in worst.items()}
 
 
+def check_bf16_encoder_s2d(device, seed=3):
+    """The encoder's stride-2 Conv2d / ConvTranspose2d (sftmd_arch.py:745-749) in the stride-1 forms of csrc/s2d.hip
+    (space-to-depth image + expanded kernel; expanded kernel + PixelShuffle(2) epilogue) against torch's own strided and
+    transposed convolutions of the same bf16-rounded operands: forward to 2^-8 of the largest value, and - through the
+    tape operators of graph.py - the input gradient (2^-7: two roundings) and the fp32 weight / bias gradients (2e-3: the
+    LeakyReLU backward rounds dy * 0.2 to bf16 before the weight gradient sums it; measured 2e-4 .. 3e-4; a misplaced
+    kernel slice would be an O(1) error).
+    Odd and even frame sizes; the fp32 and the bf16 flavour of the space-to-depth input."""
+    from dasr_amd import graph, tape as tp
+    gen = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    worst = {}
+    for (cin, cout, B, H, W, x_bf16) in [(32, 64, 2, 12, 16, False), (64, 128, 1, 7, 9, True), (32, 32, 1, 5, 34, True)]:
+        x = _bf(rn(B, cin, H, W))
+        w = _bf(rn(cout, cin, 3, 3) * (1.0 / math.sqrt(9 * cin)))
+        bias = rn(cout) * 0.1
+        xt, wt, bt = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        ref = F.leaky_relu(F.conv2d(xt, wt, bt, stride=2, padding=1), 0.2)
+        dy = _bf(rn(*ref.shape))
+        gx, gw, gb = torch.autograd.grad(ref, (xt, wt, bt), dy)
+        t = tp.Tape(True, BF16)
+        xv = tp.Var(nhwc(x).to(device).to(BF16 if x_bf16 else torch.float32), True)
+        wv = tp.Var(ops.pack_hwio(w.permute(2, 3, 1, 0).contiguous().to(device)), True)
+        bv = tp.Var(bias.to(device), True)
+        y = graph.conv(t, graph.space_to_depth2(t, xv), graph.expand_s2(t, wv), bv, act=ops.ACT_LRELU)
+        assert y.data.dtype == BF16 and tuple(y.data.shape) == tuple(nhwc(ref).shape), (y.data.shape, ref.shape)
+        e = (nchw(y.data.float().cpu()) - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
+        y.grad = nhwc(dy).to(device).to(BF16)
+        t.backward()
+        e1 = (nchw(xv.grad.float().cpu()) - gx).abs().max().item() / gx.abs().max().item()
+        e2 = rel_max(wv.grad.permute(3, 2, 0, 1), gw)
+        e3 = rel_max(bv.grad, gb)
+        assert xv.grad.dtype == xv.data.dtype and wv.grad.dtype == torch.float32
+        assert e <= 2.0 ** -8 and e1 <= 2.0 ** -7 and e2 <= 2e-3 and e3 <= 2e-3, ("s2", cin, cout, H, W, e, e1, e2, e3)
+        worst["s2 %d->%d %dx%d" % (cin, cout, H, W)] = (e, e1, e2, e3)
+    for (cin, cout, B, H, W) in [(128, 32, 1, 4, 5), (32, 64, 2, 6, 8)]:
+        x = _bf(rn(B, cin, H, W))
+        w = _bf(rn(cin, cout, 3, 3) * (1.0 / math.sqrt(9 * cin)))          # ConvTranspose2d: [Cin][Cout][kh][kw]
+        bias = rn(cout) * 0.1
+        xt, wt, bt = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        ref = F.leaky_relu(F.conv_transpose2d(xt, wt, bt, stride=2, padding=1, output_padding=1), 0.2)
+        dy = _bf(rn(*ref.shape))
+        gx, gw, gb = torch.autograd.grad(ref, (xt, wt, bt), dy)
+        t = tp.Tape(True, BF16)
+        xv = tp.Var(nhwc(x).to(device).to(BF16), True)
+        # the packed form of a transposed kernel is HWIO of w[ci][co][kh][kw] (ops.weight_pack(transposed=True))
+        wv = tp.Var(ops.pack_hwio(w.permute(2, 3, 0, 1).contiguous().to(device)), True)
+        bv = tp.Var(bias.to(device), True)
+        w4, b4 = graph.expand_t2(t, wv, bv)
+        y = graph.conv(t, xv, w4, b4, act=ops.ACT_LRELU, ps_r=2)
+        assert y.data.dtype == BF16 and tuple(y.data.shape) == tuple(nhwc(ref).shape), (y.data.shape, ref.shape)
+        e = (nchw(y.data.float().cpu()) - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
+        y.grad = nhwc(dy).to(device).to(BF16)
+        t.backward()
+        e1 = (nchw(xv.grad.float().cpu()) - gx).abs().max().item() / gx.abs().max().item()
+        e2 = rel_max(wv.grad.permute(2, 3, 0, 1), gw)
+        e3 = rel_max(bv.grad, gb)
+        assert e <= 2.0 ** -8 and e1 <= 2.0 ** -7 and e2 <= 2e-3 and e3 <= 2e-3, ("t2", cin, cout, H, W, e, e1, e2, e3)
+        worst["t2 %d->%d %dx%d" % (cin, cout, H, W)] = (e, e1, e2, e3)
+    return {k: tuple(round(v, 7) for v in vs) for k, vs in worst.items()}
+
+
 def digest_cosine(named_grads, golden, prefix, skip=()):
     dot = na = nb = 0.0
     for k, gten in named_grads:
@@ -1220,7 +1282,8 @@ def check_bf16_depthnet_case(case, device, dpsnr_tol=0.02):
     lloss, _ = digest_global_rel_l2(named, g, "g.", skip=ZERO_GRAD_KEYS)
     cos = digest_cosine(named, g, "g.", skip=ZERO_GRAD_KEYS)
     assert lloss <= loss_gate and cos >= cos_min, ("bf16 loss grads", case["name"], lloss, cos)
-    assert abs(l_pix.item() - float(g["l_pix"])) <= 2e-4 and abs(l_dyn.item() - float(g["l_dyn"])) <= 2e-3
+    assert abs(l_pix.item() - float(g["l_pix"])) <= 1e-3 and abs(l_dyn.item() - float(g["l_dyn"])) <= 2e-3, \
+        ("bf16 loss values", case["name"], l_pix.item() - float(g["l_pix"]), l_dyn.item() - float(g["l_dyn"]))
     if device != "cpu":
         net.set_compute_dtype(torch.float32)
         with torch.no_grad(), torch.autocast("cuda", dtype=BF16):

@@ -191,6 +191,11 @@ def test_bf16_conv_variants():
 
 
 @pytest.mark.gpu
+def test_bf16_encoder_s2d():
+    print(pc.check_bf16_encoder_s2d("cuda"))
+
+
+@pytest.mark.gpu
 def test_bf16_ops_vs_fp32_kernels():
     print(pc.check_bf16_ops_vs_fp32_kernels("cuda"))
 

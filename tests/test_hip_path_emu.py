@@ -1,3 +1,4 @@
+import os
 """The HIP kernel sources, executed by the CPU kernel emulator (tests/hipemu), against the reference's
 golden vectors and the oracle.  These run without a GPU; tests/test_gpu_parity.py repeats them on the
 MI355X through libdasr_hip.so."""
@@ -106,10 +107,21 @@ def test_bf16_conv_variants(emu):
     print(pc.check_bf16_conv_variants("cpu"))
 
 
+def test_bf16_encoder_s2d(emu):
+    print(pc.check_bf16_encoder_s2d("cpu"))
+
+
 @pytest.mark.parametrize("name", ["x8_nb4", "x4_nb4"])
 def test_bf16_depthnet(emu, name):
     case = [c for c in DEPTHNET_CASES if c["name"] == name][0]
     print(name, pc.check_bf16_depthnet_case(case, "cpu"))
+    if os.environ.get("DASR_TEST_FP32_ENCODER"):       # the same check with the encoder on the fp32 gather kernels
+        from dasr_amd import graph
+        graph.ENCODER_S2D = False
+        try:
+            print(name, "fp32 encoder", pc.check_bf16_depthnet_case(case, "cpu"))
+        finally:
+            graph.ENCODER_S2D = True
 
 
 def test_bf16_ops_vs_fp32_kernels(emu):
