@@ -1,7 +1,15 @@
 export TMPDIR=/tmp
-O=gpurun_out/r2s; mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "bf16" 2>&1 | tail -2
-python bench.py --config c3 --steps 3 --warmup 1 | cut -c1-200
-python bench.py --config c4 --steps 5 --warmup 2 | cut -c1-200
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_c3s -o bench --output-format csv -- python3 bench.py --config c3 --steps 2 --warmup 1 --serial > $O/bench_c3_serial.json 2> $O/bench_c3_serial.err; echo "prof c3 rc=$?"
-python tools/kstats.py $O/prof_c3s 48 > $O/kstats_c3_serial.txt
+O=gpurun_out/r2s; mkdir -p $O; rm -rf $O/pmcA $O/pmcB
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS -d $O/pmcA -o p --output-format csv -- python3 tools/bench_one_bf16.py fwd > /dev/null 2> $O/pmcA.err; echo "A rc=$?"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmcB -o p --output-format csv -- python3 tools/bench_one_bf16.py fwd > /dev/null 2> $O/pmcB.err; echo "B rc=$?"
+python - <<'PY'
+import csv, glob, collections
+for d in ("gpurun_out/r2s/pmcA", "gpurun_out/r2s/pmcB"):
+    agg = collections.defaultdict(list)
+    for path in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            if "k_conv3x3_bf16" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in sorted(agg.items()):
+        print(d[-4:], k, sum(v) / len(v), len(v))
+PY
