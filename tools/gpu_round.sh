@@ -19,3 +19,7 @@ timeout -k 10 200 python tools/bench_ops.py --batch 16 > $O/ops_b16.txt 2>&1; ec
 timeout -k 10 200 python tools/bench_ops.py --batch 32 --only sean,c1 > $O/ops_b32.txt 2>&1
 timeout -k 10 200 python tools/bench_ops_bf16.py > $O/ops_bf16_c3.txt 2>&1; echo "ops bf16 rc=$?"
 ls $O
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_c3s -o bench --output-format csv -- python3 bench.py --config c3 --steps 2 --warmup 1 --serial > $O/bench_c3_serial.json 2> $O/bench_c3_serial.err; echo "prof c3 serial rc=$?"
+python tools/kstats.py $O/prof_c3s 60 > $O/kstats_c3_serial.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_c2s -o bench --output-format csv -- python3 bench.py --steps 3 --warmup 1 --serial --no-cpu-baseline --no-b32 > $O/bench_c2_serial.json 2> $O/bench_c2_serial.err; echo "prof c2 serial rc=$?"
+python tools/kstats.py $O/prof_c2s 60 > $O/kstats_c2_serial.txt
