@@ -330,10 +330,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.optimize_parameters(lq, gt, dm, mk)
+    host_enqueue = time.perf_counter() - t0       # the host has issued every launch of the timed steps (no sync in a step)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    note("host enqueue %.1f ms/step of %.1f ms/step" % (host_enqueue / args.steps * 1e3, elapsed / args.steps * 1e3))
     timer.enabled = False
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

@@ -37,6 +37,23 @@ __device__ __forceinline__ bf16_t dasr_f2bf(float f) { return (bf16_t)f; }
 __device__ __forceinline__ float dasr_bf2f(bf16_t b) { return (float)b; }
 #endif
 
+// two floats -> two bf16 with one v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#ifdef DASR_HIPEMU
+static inline bf16x2_t dasr_f2bf2(float a, float b) {
+    bf16x2_t r;
+    r[0] = dasr_f2bf(a);
+    r[1] = dasr_f2bf(b);
+    return r;
+}
+#else
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x2_t dasr_f2bf2(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_convertvector(v, bf16x2_t);
+}
+#endif
+
 // ---- 4 consecutive elements <-> float4 -------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
 template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *(const float4*)p; }

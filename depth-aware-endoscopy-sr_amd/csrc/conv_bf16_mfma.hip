@@ -74,13 +74,29 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
     const int x0 = (tile % tiles_x) * CB_TW, y0 = (tile / tiles_x) * CB_TH;
     const int b = gt / (tiles_x * tiles_y), n0 = (kq % nsl) * NTILE;
 
+    // The accumulators start at the bias (a lane's 16 registers of an accumulator belong to ONE output channel - four
+    // consecutive ones per register quad in the transposed layout), not at zero: 64 v_add_f32 less per wave in an epilogue
+    // that costs as many VALU cycles as the MFMAs of a 64-channel layer.
     f32x16 acc[CB_MTW][NT];
 #pragma unroll
-    for (int m = 0; m < CB_MTW; ++m)
+    for (int n = 0; n < NT; ++n) {
+        float bq[16];
+        if (TD) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bv = a.bias ? *(const float4*)(a.bias + n0 + 32 * n + 8 * g4 + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bq[4 * g4] = bv.x; bq[4 * g4 + 1] = bv.y; bq[4 * g4 + 2] = bv.z; bq[4 * g4 + 3] = bv.w;
+            }
+        } else {
+            const float bv = a.bias ? a.bias[n0 + 32 * n + li] : 0.f;      // ONE load: a lane's 16 registers are one channel
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) bq[r] = bv;
+        }
+#pragma unroll
+        for (int m = 0; m < CB_MTW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = bq[r];
+    }
 
     constexpr int NINP = CB_HALO_H * CB_HALO_W * PPX;             // 16-byte pieces of the halo tile
     constexpr int NWTP = 9 * NTILE * PPX;
@@ -93,23 +109,42 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
     const BufRsrc rx = dasr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.Cin, (size_t)a.H * a.W * a.Cin * sizeof(bf16_t));
     const BufRsrc rw = dasr_make_rsrc(wsrc, (size_t)9 * a.Cin * a.Cout * sizeof(bf16_t));
     unsigned offx[NIN], offw[NWT];
+    {
+        // piece u of this thread is pixel (tid / PPX + u * NTHR / PPX) of the halo tile: the pixel index is decoded ONCE (one
+        // division by the tile width) and advanced by a compile-time (rows, columns) step per piece - 32-bit adds and
+        // selects.  (Decoded per piece - a division, two 32-bit multiplies lowered to v_mad_u64_u32, an exec-masked select -
+        // the prologue cost ~1500 cycles per wave: a third of the MFMA time of a 64-channel layer's workgroup.)
+        constexpr int DPIX = NTHR / PPX, DROW = DPIX / CB_HALO_W, DCOL = DPIX % CB_HALO_W;
+        const int pixb = a.Cin * (int)sizeof(bf16_t), rowb = a.W * pixb;
+        int prow = (tid / PPX) / CB_HALO_W, pcol = (tid / PPX) % CB_HALO_W;
+        int off = (y0 - 1 + prow) * rowb + (x0 - 1 + pcol) * pixb + 8 * (tid % PPX) * (int)sizeof(bf16_t);
 #pragma unroll
-    for (int u = 0; u < NIN; ++u) {
-        const int idx = tid + NTHR * u;
-        const int pix = idx / PPX, q4 = idx % PPX;
-        const int gy = y0 + pix / CB_HALO_W - 1, gx = x0 + pix % CB_HALO_W - 1;
-        const bool ok = idx < NINP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        offx[u] = ok ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * q4) * (int)sizeof(bf16_t)) : DASR_OOB;
-    }
-    // kernel slice as [tap][n][k], k contiguous in both modes:
-    //   forward: second half of the packed kernel, [tap][co][ci];  dgrad: first half (HWIO = [tap][n = ci_f][k = co_f]),
-    //   taps flipped
+        for (int u = 0; u < NIN; ++u) {
+            const bool ok = ((u + 1) * NTHR <= NINP || tid + NTHR * u < NINP) && (unsigned)(y0 - 1 + prow) < (unsigned)a.H &&
+                            (unsigned)(x0 - 1 + pcol) < (unsigned)a.W;
+            offx[u] = ok ? (unsigned)off : DASR_OOB;
+            prow += DROW;
+            pcol += DCOL;
+            off += DROW * rowb + DCOL * pixb;
+            const bool wrap = pcol >= CB_HALO_W;
+            prow += wrap ? 1 : 0;
+            pcol -= wrap ? CB_HALO_W : 0;
+            off += wrap ? rowb - CB_HALO_W * pixb : 0;
+        }
+        // kernel slice as [tap][n][k], k contiguous in both modes:
+        //   forward: second half of the packed kernel, [tap][co][ci];  dgrad: first half (HWIO = [tap][n = ci_f][k = co_f]),
+        //   taps flipped.  Piece idx = tid + NTHR * u: column piece idx % PPX, row (idx / PPX) % NTILE of tap idx / (NTILE * PPX)
+        //   - powers of two: shifts; one 24-bit multiply for the tap.
+        const int tapb = a.Cout * a.Cin * (int)sizeof(bf16_t);
 #pragma unroll
-    for (int u = 0; u < NWT; ++u) {
-        const int idx = tid + NTHR * u;
-        const int q4 = idx % PPX, nl = (idx / PPX) % NTILE, tap = idx / (NTILE * PPX);
-        const int tsrc = WMODE == 0 ? tap : 8 - tap;
-        offw[u] = idx < NWTP ? (unsigned)((((tsrc * a.Cout + n0 + nl) * a.Cin) + 8 * q4) * (int)sizeof(bf16_t)) : DASR_OOB;
+        for (int u = 0; u < NWT; ++u) {
+            const int idx = tid + NTHR * u;
+            const int q4 = idx % PPX, nl = (idx / PPX) % NTILE, tap = idx / (NTILE * PPX);
+            const int tsrc = WMODE == 0 ? tap : 8 - tap;
+            offw[u] = ((u + 1) * NTHR <= NWTP || idx < NWTP)
+                          ? (unsigned)(DASR_MUL24(tsrc, tapb) + ((n0 + nl) * a.Cin + 8 * q4) * (int)sizeof(bf16_t))
+                          : DASR_OOB;
+        }
     }
     auto prefetch = [&](int c0) {
         const unsigned cb = (unsigned)c0 * (unsigned)sizeof(bf16_t);
@@ -223,9 +258,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bv = a.bias ? *(const float4*)(a.bias + n0 + 32 * n + 8 * g + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    float o[4] = {acc[m][n][4 * g] + bv.x, acc[m][n][4 * g + 1] + bv.y, acc[m][n][4 * g + 2] + bv.z,
-                                  acc[m][n][4 * g + 3] + bv.w};
+                    float o[4] = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
                     bf16x4 ov;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -263,13 +296,21 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
                 const int gy = y0 + CB_MTW * wv + m;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const float bv = a.bias ? a.bias[n0 + 32 * n + li] : 0.f;
+                    // activation as one or two instructions per element (bias is already in the accumulator): ReLU =
+                    // max(v, 0); LeakyReLU / none = max(v, slope * v) with slope 0.2 / 1 (slope <= 1).  Two elements per
+                    // v_cvt_pk_bf16_f32; the halves go to their rows with ds_write_b16 / ds_write_b16_d16_hi.
+                    auto put = [&](int r, float v0, float v1) {
+                        const bf16x2_t pk = dasr_f2bf2(v0, v1);
+                        sH[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPH + 32 * n + li] = pk[0];
+                        sH[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh) * EPH + 32 * n + li] = pk[1];
+                    };
+                    if (is_relu) {                  // one wave-uniform branch per 16 elements, not one per pair
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[m][n][r] + bv;
-                        const float neg = is_relu ? 0.f : v * slope;
-                        v = v > 0.f ? v : neg;
-                        sH[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPH + 32 * n + li] = dasr_f2bf(v);
+                        for (int r = 0; r < 16; r += 2) put(r, fmaxf(acc[m][n][r], 0.f), fmaxf(acc[m][n][r + 1], 0.f));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2)
+                            put(r, fmaxf(acc[m][n][r], acc[m][n][r] * slope), fmaxf(acc[m][n][r + 1], acc[m][n][r + 1] * slope));
                     }
                 }
                 DASR_WAVE_SYNC();
@@ -294,10 +335,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
             const int gy = y0 + CB_MTW * wv + m;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const float bv = a.bias ? a.bias[n0 + 32 * n + li] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    sE[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * n + li] = acc[m][n][r] + bv;
+                    sE[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * n + li] = acc[m][n][r];
             }
             DASR_WAVE_SYNC();
             if (gy < a.H) {
@@ -369,13 +409,12 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv3x3_bf16(ConvBf16Args a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int co = n0 + 32 * n + li;
-            const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (gx >= a.W) continue;
                 const size_t pidx = (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co;
-                float v = acc[m][n][r] + bv;
+                float v = acc[m][n][r];
                 if (a.residual) v += dasr_bf2f(a.residual[pidx]);
                 v = dasr_act(v, a.act);
                 size_t o = pidx;

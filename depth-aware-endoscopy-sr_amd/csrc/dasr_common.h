@@ -13,6 +13,7 @@
 #define DASR_DYN_SMEM(name) char* name = hipemu::dyn_smem
 #define DASR_DEVICE_BUILD 0
 #define DASR_UNIFORM(x) (x)
+#define DASR_MUL24(a, b) ((a) * (b))
 #define DASR_SCHED_BARRIER() ((void)0)
 #define DASR_WAVE_SYNC() hipemu::wave_barrier()
 #else
@@ -23,6 +24,7 @@
 #define DASR_DEVICE_BUILD 1
 // a value the program knows to be the same in every lane of the wave: move it to an SGPR
 #define DASR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#define DASR_MUL24(a, b) __mul24((a), (b))      /* operands below 2^23 in magnitude: v_mul_i32_i24, full rate */
 #define DASR_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // Ordering point between LDS accesses of ONE wave that communicate across its lanes (wave-private LDS slices): the
 // hardware executes a wave's DS instructions in issue order, so no s_barrier is needed - only that the compiler keeps the
