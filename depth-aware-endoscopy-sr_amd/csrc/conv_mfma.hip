@@ -18,6 +18,7 @@
 // store instruction writes two 128-byte runs; bias, residual, activation and the PixelShuffle index map are
 // applied there.
 #include "dasr_common.h"
+#include "bf16.h"
 #include "conv_kernels.h"
 
 #define CM_TW 32
@@ -105,48 +106,72 @@ __global__ void __launch_bounds__(32 * CM_TH) k_conv3x3_mfma(ConvMfmaArgs a) {
     constexpr int NWT = (9 * NTILE * 4 + NTHR - 1) / NTHR;
     float4 pin[NIN], pwt[NWT];
     const float* wsrc = WMODE == 0 ? a.w + (size_t)9 * a.Cin * a.Cout : a.w;
-    auto prefetch = [&](int c0) {
+    // Staging addresses are computed ONCE per workgroup, as in the bf16 kernel (conv_bf16_mfma.hip): a byte offset per
+    // 16-byte piece from the sample's / the kernel slice's base, DASR_OOB for halo pixels outside the image (the buffer
+    // load's range check returns the zero padding), so that the per-chunk prefetch is "add the chunk offset, load".  The
+    // pixel index of a thread's first piece is decoded with one division and advanced by a compile-time (rows, columns)
+    // step.  (Per chunk and piece it was: two divisions, a 64-bit address, four compares and an exec-masked load - ~450
+    // VALU instructions per thread and chunk next to 72 MFMAs per wave.)
+    constexpr int NINP = CM_HALO_H * CM_HALO_W * 4, NWTP = 9 * NTILE * 4;
+    const BufRsrc rx = dasr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.Cin, (size_t)a.H * a.W * a.Cin * sizeof(float));
+    const BufRsrc rw = dasr_make_rsrc(wsrc, (size_t)9 * a.Cin * a.Cout * sizeof(float));
+    unsigned offx[NIN], offw[NWT];
+    {
+        constexpr int DPIX = NTHR / 4, DROW = DPIX / CM_HALO_W, DCOL = DPIX % CM_HALO_W;
+        const int pixb = a.Cin * (int)sizeof(float), rowb = a.W * pixb;
+        int prow = (tid >> 2) / CM_HALO_W, pcol = (tid >> 2) % CM_HALO_W;
+        int off = (y0 - 1 + prow) * rowb + (x0 - 1 + pcol) * pixb + 16 * (tid & 3);
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
-            const int idx = tid + NTHR * u;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < CM_HALO_H * CM_HALO_W * 4) {
-                const int pix = idx >> 2, q4 = idx & 3;
-                const int gy = y0 + pix / CM_HALO_W - 1, gx = x0 + pix % CM_HALO_W - 1;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * q4);
-            }
-            pin[u] = v;
+            const bool ok = ((u + 1) * NTHR <= NINP || tid + NTHR * u < NINP) && (unsigned)(y0 - 1 + prow) < (unsigned)a.H &&
+                            (unsigned)(x0 - 1 + pcol) < (unsigned)a.W;
+            offx[u] = ok ? (unsigned)off : DASR_OOB;
+            prow += DROW;
+            pcol += DCOL;
+            off += DROW * rowb + DCOL * pixb;
+            const bool wrap = pcol >= CM_HALO_W;
+            prow += wrap ? 1 : 0;
+            pcol -= wrap ? CM_HALO_W : 0;
+            off += wrap ? rowb - CM_HALO_W * pixb : 0;
         }
         // weight slice as [tap][n][k]: both modes read a [tap][n][k]-ordered source with k contiguous
         //   forward: second half of the packed kernel, [tap][co][ci]
         //   dgrad  : first half (HWIO of the forward conv = [tap][n = ci_f][k = co_f]) with the taps flipped
+        const int tapb = a.Cout * a.Cin * (int)sizeof(float);
 #pragma unroll
         for (int u = 0; u < NWT; ++u) {
             const int idx = tid + NTHR * u;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < 9 * NTILE * 4) {
-                const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
-                const int tsrc = WMODE == 0 ? tap : 8 - tap;
-                v = *(const float4*)(wsrc + ((size_t)tsrc * a.Cout + n0 + nl) * a.Cin + c0 + 4 * q4);
-            }
-            pwt[u] = v;
+            const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
+            const int tsrc = WMODE == 0 ? tap : 8 - tap;
+            offw[u] = ((u + 1) * NTHR <= NWTP || idx < NWTP)
+                          ? (unsigned)(DASR_MUL24(tsrc, tapb) + ((n0 + nl) * a.Cin + 4 * q4) * (int)sizeof(float))
+                          : DASR_OOB;
         }
+    }
+    auto ld16 = [&](BufRsrc r, unsigned off) {
+        const u32x4_t v = dasr_buffer_load16(r, off);
+        float4 f;
+        __builtin_memcpy(&f, &v, 16);
+        return f;
     };
+    auto prefetch = [&](int c0) {
+        const unsigned cb = (unsigned)c0 * (unsigned)sizeof(float);
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) pin[u] = ld16(rx, offx[u] + cb);
+#pragma unroll
+        for (int u = 0; u < NWT; ++u) pwt[u] = ld16(rw, offw[u] + cb);
+    };
+    // LDS images: piece idx goes to (idx / 4) * CM_CKP + 4 * (idx % 4) of its tile - a per-thread base plus a compile-time
+    // step per u (the weight tile's [tap][n] rows are consecutive, so it is one flat array of 16-byte pieces as well)
+    float* const lin = sIn + (tid >> 2) * CM_CKP + 4 * (tid & 3);
+    float* const lwt = sW + (tid >> 2) * CM_CKP + 4 * (tid & 3);
     auto commit = [&]() {
 #pragma unroll
-        for (int u = 0; u < NIN; ++u) {
-            const int idx = tid + NTHR * u;
-            if (idx < CM_HALO_H * CM_HALO_W * 4) *(float4*)(sIn + (idx >> 2) * CM_CKP + 4 * (idx & 3)) = pin[u];
-        }
+        for (int u = 0; u < NIN; ++u)
+            if ((u + 1) * NTHR <= NINP || tid + NTHR * u < NINP) *(float4*)(lin + u * (NTHR / 4) * CM_CKP) = pin[u];
 #pragma unroll
-        for (int u = 0; u < NWT; ++u) {
-            const int idx = tid + NTHR * u;
-            if (idx < 9 * NTILE * 4) {
-                const int q4 = idx & 3, nl = (idx >> 2) % NTILE, tap = idx / (NTILE * 4);
-                *(float4*)(sW + (tap * NTILE + nl) * CM_CKP + 4 * q4) = pwt[u];
-            }
-        }
+        for (int u = 0; u < NWT; ++u)
+            if ((u + 1) * NTHR <= NWTP || tid + NTHR * u < NWTP) *(float4*)(lwt + u * (NTHR / 4) * CM_CKP) = pwt[u];
     };
     CM_T_DECL;
     prefetch(0);
@@ -377,9 +402,10 @@ static size_t conv_mfma_lds(int NT, int TH) {
     return sizeof(float) * (size_t)((TH + 2) * CM_HALO_W * CM_CKP + 9 * 32 * NT * CM_CKP);
 }
 
+// (a sample's input is addressed through a buffer descriptor with 32-bit byte offsets: below 2 GiB)
 bool conv_mfma_supported(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin % CM_CK) == 0 &&
-           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo && (size_t)g.H * g.W * g.Cin * sizeof(float) < ((size_t)1 << 31);
 }
 
 static int cm_tile_rows(int B, int H, int W, int Cout) {
@@ -479,7 +505,7 @@ int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float
 }
 bool conv_mfma_dgrad_supported(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cout % CM_CK) == 0 &&
-           (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+           (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo && (size_t)g.H * g.W * g.Cout * sizeof(float) < ((size_t)1 << 31);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
