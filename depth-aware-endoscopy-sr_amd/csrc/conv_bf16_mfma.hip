@@ -436,13 +436,19 @@ static size_t conv_bf16_lds(int NT, int NW, int MTW, int CK) {
     return main_b > ep_b ? main_b : ep_b;
 }
 
+// (tensors are addressed through buffer descriptors with 32-bit byte offsets: a sample below 2 GiB; one tap of the kernel
+// below 2^23 bytes: its offset is a 24-bit multiply)
+static bool conv_bf16_ranges_ok(const ConvGeom& g) {
+    const size_t cmax = g.Cin > g.Cout ? g.Cin : g.Cout;
+    return (size_t)g.H * g.W * cmax * sizeof(bf16_t) < ((size_t)1 << 31) && (size_t)g.Cin * g.Cout * sizeof(bf16_t) < ((size_t)1 << 23);
+}
 bool conv_bf16_supported(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin % 32) == 0 &&
-           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo && conv_bf16_ranges_ok(g);
 }
 bool conv_bf16_dgrad_supported(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cout % 32) == 0 &&
-           (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo;
+           (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo && conv_bf16_ranges_ok(g);
 }
 
 // Tile variants measured on the MI355X at the x4 / B=32 shapes (tools/bench_ops_bf16.py, profiles/r02_conv_bf16_variants.txt):

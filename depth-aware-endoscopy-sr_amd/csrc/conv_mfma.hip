@@ -405,7 +405,8 @@ static size_t conv_mfma_lds(int NT, int TH) {
 // (a sample's input is addressed through a buffer descriptor with 32-bit byte offsets: below 2 GiB)
 bool conv_mfma_supported(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cin % CM_CK) == 0 &&
-           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo && (size_t)g.H * g.W * g.Cin * sizeof(float) < ((size_t)1 << 31);
+           (g.Cout % 32) == 0 && g.H == g.Ho && g.W == g.Wo && (size_t)g.H * g.W * g.Cin * sizeof(float) < ((size_t)1 << 31) &&
+           (size_t)g.Cin * g.Cout * sizeof(float) < ((size_t)1 << 23);      // one tap of the kernel: a 24-bit multiply
 }
 
 static int cm_tile_rows(int B, int H, int W, int Cout) {
@@ -505,7 +506,8 @@ int conv_mfma_dgrad(const ConvGeom& g, const float* dconv, const float* w, float
 }
 bool conv_mfma_dgrad_supported(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.transposed && (g.Cout % CM_CK) == 0 &&
-           (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo && (size_t)g.H * g.W * g.Cout * sizeof(float) < ((size_t)1 << 31);
+           (g.Cin % 32) == 0 && g.H == g.Ho && g.W == g.Wo && (size_t)g.H * g.W * g.Cout * sizeof(float) < ((size_t)1 << 31) &&
+           (size_t)g.Cin * g.Cout * sizeof(float) < ((size_t)1 << 23);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
