@@ -255,6 +255,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: c2 16, c3 32, c4 16, c5 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the forward-only batch-32 roofline pass")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="experiment: weight gradients on a third stream (graph.WGRAD_STREAM; measured slower at c2)")
     ap.add_argument("--serial", action="store_true",
                     help="profiling aid: depth branch on the main stream (no co-running kernels, so a rocprofv3 kernel trace "
                          "shows isolated kernel durations); the reported value is then NOT the product configuration")
@@ -277,6 +279,9 @@ def main():
         group = dist.group.WORLD
 
     cfg = CONFIGS[args.config]
+    if args.wgrad_stream:
+        from dasr_amd import graph as _graph_mod2
+        _graph_mod2.WGRAD_STREAM = True
     if args.serial:
         from dasr_amd import graph as _graph_mod
         _graph_mod.SIDE_STREAM = False

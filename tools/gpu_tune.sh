@@ -1,1 +1,4 @@
-python tools/prof_small_ops.py bf16 2>&1 | grep -v amdgpu.ids | head -45
+python bench.py --config c3 --steps 3 --warmup 1 | cut -c1-160
+python bench.py --config c3 --steps 3 --warmup 1 --wgrad-stream | cut -c1-160
+python bench.py --config c4 --steps 5 --warmup 2 | cut -c1-160
+python bench.py --config c4 --steps 5 --warmup 2 --wgrad-stream | cut -c1-160
