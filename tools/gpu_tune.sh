@@ -1,4 +1,4 @@
-python bench.py --config c3 --steps 3 --warmup 1 | cut -c1-160
-python bench.py --config c3 --steps 3 --warmup 1 --wgrad-stream | cut -c1-160
-python bench.py --config c4 --steps 5 --warmup 2 | cut -c1-160
-python bench.py --config c4 --steps 5 --warmup 2 --wgrad-stream | cut -c1-160
+O=gpurun_out/r2u; mkdir -p $O
+timeout -k 10 1000 python -m pytest tests -m gpu -q -rA -s > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-200 $O/bench.json
