@@ -432,6 +432,33 @@ __device__ __forceinline__ void sean_gather(const float* sD, const unsigned char
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k[tap]) * 64 + 4 * cq));
 }
+// Interior pixels: when the nine region bytes of a pixel's 3x3 neighbourhood are equal (most pixels: depth regions are
+// blobs), gamma1 / beta1 are one row of a per-region table S[s][k] = bias + D[s][0][k] + ... + D[s][8][k] (summed in the
+// gather's own order: bit-identical) - two LDS reads instead of eighteen and no adds.  Taken when EVERY lane of the wave
+// is interior (a vote), so the wave does not run both paths.
+__device__ __forceinline__ void sean_gather_interior(const float* sD, const float* sS, const unsigned char* sR, int K,
+                                                     int K1, int ly, int lx, int cq, float4 bg, float4 bb, float4& g1,
+                                                     float4& b1) {
+    int k[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) k[tap] = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
+    bool same = true;
+#pragma unroll
+    for (int tap = 1; tap < 9; ++tap) same = same && k[tap] == k[0];
+    if (__all(same ? 1 : 0)) {             // (a pixel outside the image sees nine "no region" bytes: clamped, result unused)
+        const int kk = k[0] < K ? k[0] : K - 1;
+        g1 = *(const float4*)(sS + (0 * K + kk) * 64 + 4 * cq);
+        b1 = *(const float4*)(sS + (1 * K + kk) * 64 + 4 * cq);
+        return;
+    }
+    g1 = bg;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k[tap]) * 64 + 4 * cq));
+    DASR_SCHED_BARRIER();
+    b1 = bb;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k[tap]) * 64 + 4 * cq));
+}
 // the same with the biases already folded into the tap-0 rows (sean_stage_D with bias pointers)
 __device__ __forceinline__ void sean_gather_folded(const float* sD, const unsigned char* sR, int K1, int ly, int lx,
                                                    int cq, float4& g1, float4& b1) {
@@ -623,7 +650,7 @@ template <> struct SeanBwdCfg<bf16_t> { static constexpr int NP = 1; };   // bf1
 template <> struct SeanBwdCfg<float>  { static constexpr int NP = 3; };   // three exact pieces
 // tile rows: as many as the two G buffers leave room for beside the D table (160 KB of LDS)
 __host__ __device__ constexpr int sean_bwd_lds_bytes(int K, int TH, int NP) {
-    return 4 * (18 * (K + 1) * 64 + 8 * 18 * 16) + 2 * (2 * NP * TH * 32 * 160) + 3 * (((TH + 2) * 34 + 15) / 16 * 16) + 16;
+    return 4 * (18 * (K + 1) * 64 + 8 * 18 * 16 + 2 * K * 64) + 2 * (2 * NP * TH * 32 * 160) + 3 * (((TH + 2) * 34 + 15) / 16 * 16) + 16;
 }
 #define SB16_GST 160           // sG pixel stride in bf16 elements (320 B: the 4 pixel rows of a transposed read fall in
                                // four disjoint 64-byte bank ranges)
@@ -673,7 +700,8 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     float* sD = (float*)smem;                                   // [18][K+1][64]
     bf16_t* sG = (bf16_t*)(sD + 18 * K1 * 64);                  // [2][NP][SB_TH*SF_TW][SB16_GST]: gamma part | beta part
     float* sred = (float*)(sG + 2 * NP * PLANE);                // [8 waves][18][16] reduction scratch
-    unsigned char* sR = (unsigned char*)(sred + 8 * 18 * 16);   // [3][NRP]
+    float* sS = sred + 8 * 18 * 16;                             // [2][K][64]: bias + all nine taps of ONE region (interior pixels)
+    unsigned char* sR = (unsigned char*)(sS + 2 * g.K * 64);    // [3][NRP]
     const int b = blockIdx.y, c0 = blockIdx.z * 64;
     const int tiles_x = (g.W + SF_TW - 1) / SF_TW;
     // the wave id decides the order of the phases and guards MFMAs: keep it in an SGPR (an MFMA ignores EXEC)
@@ -700,6 +728,16 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[q][r] = 0.f;
     sean_stage_D(g, D, sD, b, c0);
+    __syncthreads();
+    // per-region table of the interior fast path (sean_gather_interior): the gather's own summation order
+    for (int e = threadIdx.x; e < 2 * g.K * 16; e += blockDim.x) {
+        const int q = e & 15, k = (e >> 4) % g.K, sgb = e / (16 * g.K);
+        float4 v = zero4;
+        if (c0 + 4 * q + 3 < g.C) v = *(const float4*)((sgb == 0 ? bias_g : bias_b) + c0 + 4 * q);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) v = f4add(v, *(const float4*)(sD + ((sgb * 9 + tap) * K1 + k) * 64 + 4 * q));
+        *(float4*)(sS + (sgb * g.K + k) * 64 + 4 * q) = v;
+    }
     const int mydy = wv / 3, mydx = wv % 3;     // tap of this wave (taps 0..7); tap 8 = (2,2) is shared
     const int ly = wv / WPR, lxw = (SF_TW / WPR) * (wv % WPR);   // phase 1: this wave's tile row and first column
     // unconditional loads of the tile's 4-pixel steps (coordinates clamped into the image)
@@ -738,6 +776,9 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
         for (int u = 0; u < NST; ++u) {
             const int lx = lxw + 4 * u + ps, x = x0 + lx;
             float4 G1 = zero4, B1 = zero4;
+            // (outside the per-pixel condition: every lane of the wave takes part in the vote; the reads are LDS only)
+            float4 g1, b1;
+            sean_gather_interior(sD, sS, sRb, g.K, K1, ly, lx, cq, bg, bb, g1, b1);
             if (live && y < g.H && x < g.W) {
                 const size_t p = ((size_t)b * g.H + y) * g.W + x;
                 float4 g0 = f4(cur.g0[u]);
@@ -748,8 +789,6 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
                 }
                 if (dres) st4(dres + p * g.C + c, g0);
                 const float4 tv = f4(cur.tv[u]), g2 = f4(cur.g2[u]), b2 = f4(cur.b2[u]);
-                float4 g1, b1;
-                sean_gather(sD, sRb, K1, ly, lx, cq, bg, bb, g1, b1);
                 const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
                 const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
                 const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);

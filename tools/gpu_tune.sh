@@ -1,4 +1,7 @@
-O=gpurun_out/r2u; mkdir -p $O
-timeout -k 10 1000 python -m pytest tests -m gpu -q -rA -s > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-200 $O/bench.json
+O=gpurun_out/r2s; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "sean or bf16_ops or blocks or depthnet or other_region or soft" 2>&1 | tail -2
+python tools/bench_ops.py --batch 16 --only sean 2>&1 | grep "sean_bwd" 
+python tools/bench_ops.py --batch 32 --only sean 2>&1 | grep "sean_bwd"
+python tools/bench_ops_bf16.py --only sean 2>&1 | grep "sean_bwd"
+python tools/bench_ops_bf16.py --only sean 2>&1 | grep "sean_bwd"
+python tools/bench_ops_bf16.py --only sean --batch 16 --hw 128x160 2>&1 | grep "sean_bwd"
