@@ -1,7 +1,4 @@
-O=gpurun_out/r2s; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "sean or bf16_ops or blocks or depthnet or other_region or soft" 2>&1 | tail -2
-python tools/bench_ops.py --batch 16 --only sean 2>&1 | grep "sean_bwd" 
-python tools/bench_ops.py --batch 32 --only sean 2>&1 | grep "sean_bwd"
-python tools/bench_ops_bf16.py --only sean 2>&1 | grep "sean_bwd"
-python tools/bench_ops_bf16.py --only sean 2>&1 | grep "sean_bwd"
-python tools/bench_ops_bf16.py --only sean --batch 16 --hw 128x160 2>&1 | grep "sean_bwd"
+python bench.py --steps 40 --warmup 2 --no-cpu-baseline --no-b32 2>&1 | grep "value\|enqueue" | cut -c1-330
+python bench.py --config c3 --steps 20 --warmup 2 2>&1 | grep "value\|enqueue" | cut -c1-200
+python bench.py --config c4 --steps 60 --warmup 2 2>&1 | grep "value\|enqueue" | cut -c1-200
+rocm-smi --showmeminfo vram 2>/dev/null | grep -i "used" | head -2
