@@ -19,7 +19,9 @@ __global__ void k_dynk_stp(const float* __restrict__ st, const float* __restrict
 // One wave = one 32x32 output tile on v_mfma_f32_32x32x2_f32, operands gathered straight from global memory
 // (lane (i,h) supplies A[m0+i][2s+h] and B[2s+h][n0+i]); no LDS, no barriers.
 //
-// D[b,st,k,c] = sum_l stp[b,k,l] * W_s[c,l,tap]      M = (b,k), N = (st,c), K = l
+// D[b,st,k,c] = sum_l stp[b,k,l] * W_s[c,l,tap]      M = (b,k), N = (s,c,tap), K = l
+// The N index runs tap-fastest: W is OIHW ([c][l][3][3]), so the 32 lanes of a B-operand load read runs of nine
+// consecutive floats (one (c, l) kernel) instead of 32 words 9 KB apart (one per channel: 32 cache lines per load).
 __global__ void __launch_bounds__(256) k_dynk_D_mfma(const float* __restrict__ stp, const float* __restrict__ Wg,
                                                      const float* __restrict__ Wb, float* __restrict__ D, int B, int K,
                                                      int L, int C) {
@@ -31,7 +33,8 @@ __global__ void __launch_bounds__(256) k_dynk_D_mfma(const float* __restrict__ s
     const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
     const int m = m0 + li, n = n0 + li;
     const bool mv = m < M, nv = n < N;
-    const int st = nv ? n / C : 0, c = nv ? n % C : 0;
+    const int gb = nv ? n / (9 * C) : 0, rem = nv ? n % (9 * C) : 0;
+    const int c = rem / 9, st = gb * 9 + rem % 9;
     const float* ap = stp + (size_t)(mv ? m : 0) * L;
     const float* bp = (st >= 9 ? Wb : Wg) + (size_t)c * L * 9 + (st % 9);
     f32x16 acc;
@@ -75,7 +78,8 @@ extern "C" int dasr_dynk_fwd(const float* st, const float* A_w, const float* A_b
     DASR_RETURN_LAUNCH_STATUS();
 }
 
-// dW_s[c,l,tap] = sum_{(b,k)} dD[b,st,k,c] * stp[b,k,l]      M = (st,c), N = l, K = (b,k)
+// dW_s[c,l,tap] = sum_{(b,k)} dD[b,st,k,c] * stp[b,k,l]      M = (s,c,tap) tap-fastest, N = l, K = (b,k)
+// (tap-fastest rows: the 16 accumulator rows of a lane are stored into two 36-byte kernels instead of 16 places 9 KB apart)
 __global__ void __launch_bounds__(256) k_dynk_dW_mfma(const float* __restrict__ dD, const float* __restrict__ stp,
                                                       float* __restrict__ dWg, float* __restrict__ dWb, int B, int K,
                                                       int L, int C, float* __restrict__ zero, size_t nzero) {
@@ -89,7 +93,8 @@ __global__ void __launch_bounds__(256) k_dynk_dW_mfma(const float* __restrict__ 
     const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
     const int m = m0 + li, n = n0 + li;
     const bool mv = m < M, nv = n < N;
-    const int st = mv ? m / C : 0, c = mv ? m % C : 0;
+    const int gb = mv ? m / (9 * C) : 0, rem = mv ? m % (9 * C) : 0;
+    const int c = rem / 9, st = gb * 9 + rem % 9;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -113,8 +118,8 @@ __global__ void __launch_bounds__(256) k_dynk_dW_mfma(const float* __restrict__ 
     for (int r = 0; r < 16; ++r) {
         const int mm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (mm >= M) continue;
-        const int st2 = mm / C, c2 = mm % C;
-        (st2 >= 9 ? dWb : dWg)[((size_t)c2 * L + n) * 9 + (st2 % 9)] = acc[r];
+        const int gb2 = mm / (9 * C), rem2 = mm % (9 * C);
+        (gb2 ? dWb : dWg)[((size_t)(rem2 / 9) * L + n) * 9 + rem2 % 9] = acc[r];
     }
 }
 // dstp[b,k,l] = sum_{s,tap,c} dD[b,s,tap,k,c] * W_s[c,l,tap]      M = (b,k), N = l, K = (s,tap,c) = 18*C
@@ -136,17 +141,22 @@ __global__ void __launch_bounds__(64 * DSTP_WAVES) k_dynk_dstp_mfma(const float*
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int q = 0; q < 18 / DSTP_WAVES; ++q) {
-        const int st = wv * (18 / DSTP_WAVES) + q, tap = st % 9;
-        const float* ap = dD + (((size_t)b * 18 + st) * K + k) * C;                  // + c
-        const float* bp = (st >= 9 ? Wb : Wg) + (size_t)(nv ? n : 0) * 9 + tap;     // + c * L * 9
-        for (int c0 = lh; c0 < C; c0 += 32) {      // sixteen K steps per trip, all 32 loads issued before the first MFMA
+    {
+        // this wave's K range: its three consecutive (s, tap) slices x C channels, walked TAP-fastest (kk = 3 c + q): W is
+        // OIHW, the three taps of a (c, l) kernel are 12 consecutive bytes and the six waves of the workgroup cover its 36 -
+        // a channel-fastest walk touched a new cache line (9 KB further) on every step
+        constexpr int QW = 18 / DSTP_WAVES;
+        const int st0 = wv * QW;                                                     // QW divides 9: one s per wave
+        const float* ap = dD + (((size_t)b * 18 + st0) * K + k) * C;                 // + q * K * C + c
+        const float* bp = (st0 >= 9 ? Wb : Wg) + (size_t)(nv ? n : 0) * 9 + st0 % 9; // + c * L * 9 + q
+        const int KKW = QW * C;
+        for (int kk0 = lh; kk0 < KKW; kk0 += 32) { // sixteen K steps per trip, all 32 loads issued before the first MFMA
             float av[16], bv[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int c = c0 + 2 * u;
-                av[u] = (mv && c < C) ? ap[c] : 0.f;
-                bv[u] = (nv && c < C) ? bp[(size_t)c * L * 9] : 0.f;
+                const int kk = kk0 + 2 * u, c = kk / QW, q = kk - c * QW;
+                av[u] = (mv && kk < KKW) ? ap[(size_t)q * K * C + c] : 0.f;
+                bv[u] = (nv && kk < KKW) ? bp[(size_t)c * L * 9 + q] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
