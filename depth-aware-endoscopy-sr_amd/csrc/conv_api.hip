@@ -139,6 +139,14 @@ extern "C" int dasr_conv2d_wgrad_act(const float* x, const float* dy, const floa
                              stride, pad, transposed, stream);
 }
 
+// 1 when dasr_conv2d_wgrad_act runs its fused kernel for this geometry (no dconv_scratch needed), else 0
+extern "C" int dasr_conv2d_wgrad_act_fused(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                           int stride, int pad, int transposed) {
+    ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
+    if (check_geom(g) != DASR_OK) return 0;
+    return conv_c1_supported(g) ? 1 : 0;
+}
+
 // 1 when dasr_conv2d_dgrad_act has a kernel for this geometry
 extern "C" int dasr_conv2d_dgrad_act_supported(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
                                                int stride, int pad, int transposed, int ps_r) {

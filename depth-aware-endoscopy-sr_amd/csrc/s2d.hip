@@ -1,7 +1,7 @@
 // s2d.hip — the encoder's stride-2 layers on the bf16 stride-1 MFMA kernels (mixed-precision path only).
 //
 // Encoder.forward (sftmd_arch.py:745-749, 771-783): Conv2d 32->64->128 (3x3, stride 2, pad 1), ConvTranspose2d 128->L
-// (3x3, stride 2, pad 1, output_padding 1), Conv2d L->L (stride 2).  On fp32 activations they run on the gather kernels
+// (3x3, stride 2, pad 1, NO output_padding: its output is (2H-1) x (2W-1)), Conv2d L->L (stride 2).  On fp32 activations they run on the gather kernels
 // (conv_gather_mfma.hip: operands straight from L2, 27-50 % of the fp32 MFMA peak; 19 ms of the 174 ms bf16 step at
 // 32 x 256x320).  With bf16 activations they are re-expressed as stride-1 3x3 convolutions, which the tuned kernels of
 // conv_bf16_mfma.hip run 3-5x faster even though a quarter of the expanded taps are structural zeros:
@@ -13,6 +13,10 @@
 //   transposed conv: y[2i+a][2j+b][co] = conv3x3(x; W')[i][j][4co + 2a + b]  (PixelShuffle(2), fused in the conv epilogue)
 //                    W'[r][s][ci][4co+2a+b] = w[kh(a,r)][kw(b,s)][ci][co],  kh(0,1) = 1, kh(1,1) = 2, kh(1,2) = 0
 //                    (oy = 2 iy - 1 + kh: even rows see kh = 1 only, odd rows kh = 2 from iy = i and kh = 0 from iy = i + 1)
+//                    The PixelShuffle image is 2H x 2W; the reference's layer has no output_padding, so its last row and
+//                    column do not exist there: the consumer (space-to-depth of the next stride-2 layer) is given the
+//                    VALID extents (2H-1, 2W-1), reads zeros beyond them - the next layer's zero padding - and its
+//                    adjoint writes a zero gradient there, so nothing of the extra row / column reaches any result.
 //
 // This file: the two data movers (space-to-depth and its adjoint) and the weight expansions / gradient collapses.  The
 // convolutions themselves, their PixelShuffle / LeakyReLU epilogues and all three gradients are the existing entry points.
@@ -22,27 +26,29 @@
 // ---- space-to-depth: one thread = 4 channels of one output phase; blockIdx.y = (b, i)
 template <typename TI>
 __global__ void __launch_bounds__(256) k_space_to_depth2(const TI* __restrict__ x, bf16_t* __restrict__ y, int H, int W,
-                                                         int C, int Hs, int Ws) {
+                                                         int C, int Hs, int Ws, int Hv, int Wv) {
     const int b = blockIdx.y / Hs, i = blockIdx.y - b * Hs;
     const int c4n = C / 4, n = Ws * 4 * c4n;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
         const int c4 = idx % c4n, q = (idx / c4n) & 3, j = idx / (4 * c4n);
         const int h = 2 * i + (q >> 1), w = 2 * j + (q & 1);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h < H && w < W) v = ld4(x + (((size_t)b * H + h) * W + w) * C + 4 * c4);
+        if (h < Hv && w < Wv) v = ld4(x + (((size_t)b * H + h) * W + w) * C + 4 * c4);
         st4(y + ((((size_t)b * Hs + i) * Ws + j) * 4 + q) * C + 4 * c4, v);
     }
 }
 // adjoint: dx[b][h][w][c] (+)= dy'[b][h/2][w/2][(2(h&1) + (w&1))C + c]; blockIdx.y = (b, h)
 template <typename TO>
 __global__ void __launch_bounds__(256) k_depth_to_space2_bwd(const bf16_t* __restrict__ dy, TO* __restrict__ dx, int H,
-                                                             int W, int C, int Hs, int Ws, int accumulate) {
+                                                             int W, int C, int Hs, int Ws, int accumulate, int Hv,
+                                                             int Wv) {
     const int b = blockIdx.y / H, h = blockIdx.y - b * H;
     const int c4n = C / 4, n = W * c4n;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
         const int c4 = idx % c4n, w = idx / c4n;
         const int q = 2 * (h & 1) + (w & 1);
-        float4 v = ld4(dy + ((((size_t)b * Hs + (h >> 1)) * Ws + (w >> 1)) * 4 + q) * C + 4 * c4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);       // beyond the valid extents the forward read zeros: zero gradient
+        if (h < Hv && w < Wv) v = ld4(dy + ((((size_t)b * Hs + (h >> 1)) * Ws + (w >> 1)) * 4 + q) * C + 4 * c4);
         TO* p = dx + (((size_t)b * H + h) * W + w) * C + 4 * c4;
         if (accumulate) {
             const float4 o = ld4(p);
@@ -112,29 +118,29 @@ __global__ void __launch_bounds__(256) k_weight_collapse_t2(const float* __restr
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int dasr_space_to_depth2_bf16(const void* x, int x_is_bf16, unsigned short* y, int B, int H, int W, int C,
-                                         void* stream) {
+                                         int Hv, int Wv, void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(y);
-    DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0);
+    DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 && Hv >= 0 && Hv <= H && Wv >= 0 && Wv <= W);
     const int Hs = (H + 1) / 2, Ws = (W + 1) / 2;
     unsigned gx = dasr_cdiv((size_t)Ws * C, 256);
     if (gx > 64) gx = 64;
     const dim3 grid(gx, B * Hs);
     if (B * Hs > 65535) return DASR_E_SHAPE;
-    if (x_is_bf16) DASR_LAUNCH((k_space_to_depth2<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, H, W, C, Hs, Ws);
-    else           DASR_LAUNCH((k_space_to_depth2<float>), grid, dim3(256), 0, stream, (const float*)x, (bf16_t*)y, H, W, C, Hs, Ws);
+    if (x_is_bf16) DASR_LAUNCH((k_space_to_depth2<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, H, W, C, Hs, Ws, Hv, Wv);
+    else           DASR_LAUNCH((k_space_to_depth2<float>), grid, dim3(256), 0, stream, (const float*)x, (bf16_t*)y, H, W, C, Hs, Ws, Hv, Wv);
     DASR_RETURN_LAUNCH_STATUS();
 }
 extern "C" int dasr_depth_to_space2_bwd_bf16(const unsigned short* dy, void* dx, int dx_is_bf16, int accumulate, int B,
-                                             int H, int W, int C, void* stream) {
+                                             int H, int W, int C, int Hv, int Wv, void* stream) {
     DASR_CHECK_PTR(dy); DASR_CHECK_PTR(dx);
-    DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0);
+    DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 && Hv >= 0 && Hv <= H && Wv >= 0 && Wv <= W);
     const int Hs = (H + 1) / 2, Ws = (W + 1) / 2;
     if (B * H > 65535) return DASR_E_SHAPE;
     unsigned gx = dasr_cdiv((size_t)W * (C / 4), 256);
     if (gx > 64) gx = 64;
     const dim3 grid(gx, B * H);
-    if (dx_is_bf16) DASR_LAUNCH((k_depth_to_space2_bwd<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, Hs, Ws, accumulate);
-    else            DASR_LAUNCH((k_depth_to_space2_bwd<float>), grid, dim3(256), 0, stream, (const bf16_t*)dy, (float*)dx, H, W, C, Hs, Ws, accumulate);
+    if (dx_is_bf16) DASR_LAUNCH((k_depth_to_space2_bwd<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)dy, (bf16_t*)dx, H, W, C, Hs, Ws, accumulate, Hv, Wv);
+    else            DASR_LAUNCH((k_depth_to_space2_bwd<float>), grid, dim3(256), 0, stream, (const bf16_t*)dy, (float*)dx, H, W, C, Hs, Ws, accumulate, Hv, Wv);
     DASR_RETURN_LAUNCH_STATUS();
 }
 extern "C" int dasr_weight_expand_s2_bf16(const float* w_hwio, unsigned short* out, int Cin, int Cout, void* stream) {

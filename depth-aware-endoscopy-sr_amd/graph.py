@@ -56,7 +56,7 @@ def _folded(tape, key, tensors, make):
     cache = tape.fold_cache
     if tape.enabled or cache is None or key is None:
         return make()
-    ver = tuple((t.data_ptr(), t._version) for t in tensors)
+    ver = tuple((t.data_ptr(), ops.tensor_version(t)) for t in tensors)
     key = key + (str(tensors[0].device),)      # DataParallel replicas share the cache dict, one entry per device
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
@@ -275,10 +275,11 @@ def to_f32(tape, x):
     return out
 
 
-def space_to_depth2(tape, x):
-    """x -> bf16 space-to-depth image (ops.space_to_depth2); x fp32 or bf16."""
+def space_to_depth2(tape, x, valid_hw=None):
+    """x -> bf16 space-to-depth image (ops.space_to_depth2); x fp32 or bf16.  ``valid_hw``: extents of x that exist in the
+    reference (rows / columns beyond them read as zeros and get a zero gradient)."""
     x.uses += 1
-    out = Var(ops.space_to_depth2(x.data), x.requires_grad)
+    out = Var(ops.space_to_depth2(x.data, valid_hw), x.requires_grad)
 
     def bwd():
         if out.grad is None:
@@ -287,9 +288,9 @@ def space_to_depth2(tape, x):
         out.grad = None
         if x.requires_grad:
             if x.grad is None:
-                x.grad = ops.depth_to_space2_bwd(g, x.data.shape, x.data.dtype)
+                x.grad = ops.depth_to_space2_bwd(g, x.data.shape, x.data.dtype, valid_hw=valid_hw)
             else:
-                ops.depth_to_space2_bwd(g, x.data.shape, x.data.dtype, out=x.grad)
+                ops.depth_to_space2_bwd(g, x.data.shape, x.data.dtype, out=x.grad, valid_hw=valid_hw)
 
     tape.record(bwd)
     return out
@@ -298,7 +299,8 @@ def space_to_depth2(tape, x):
 def expand_s2(tape, wp):
     """fp32 packed kernel of a 3x3 stride-2 conv -> bf16 packed kernel of its stride-1 form on the space-to-depth image."""
     _, _, _, Cin, Cout = wp.data.shape
-    out = Var(ops.weight_expand_s2(wp.data), wp.requires_grad)
+    # (eval + no_grad: wp.data is itself the cached folded kernel, so its identity / version key this second cache level)
+    out = Var(_folded(tape, ("s2", wp.data.data_ptr()), [wp.data], lambda: ops.weight_expand_s2(wp.data)), wp.requires_grad)
 
     def bwd():
         if out.grad is None:
@@ -318,7 +320,8 @@ def expand_t2(tape, wp, bias):
     """fp32 packed kernel + bias of a 3x3 stride-2 ConvTranspose2d -> (bf16 packed kernel, bias) of the stride-1 convolution
     Cin -> 4 Cout whose PixelShuffle(2) it is."""
     _, _, _, Cin, Cout = wp.data.shape
-    w4, b4 = ops.weight_expand_t2(wp.data, bias.data if bias is not None else None)
+    w4, b4 = _folded(tape, ("t2", wp.data.data_ptr()), [wp.data] + ([bias.data] if bias is not None else []),
+                     lambda: ops.weight_expand_t2(wp.data, bias.data if bias is not None else None))
     wout = Var(w4, wp.requires_grad)
     bout = Var(b4, bias.requires_grad) if bias is not None else None
 
@@ -328,6 +331,8 @@ def expand_t2(tape, wp, bias):
         for v in (wout, bout):
             if v is not None and v.grad_event is not None:
                 torch.cuda.current_stream().wait_event(v.grad_event)
+                if v.grad is not None:
+                    v.grad.record_stream(torch.cuda.current_stream())
         gw, gb = wout.grad, (bout.grad if bout is not None else None)
         wout.grad = None
         if bout is not None:
@@ -442,7 +447,7 @@ def attached_region(mask):
         return None
     if tuple(region.shape) != (mask.shape[0],) + tuple(mask.shape[2:]) or region.device != mask.device:
         return None
-    if getattr(mask, "_dasr_version", None) != mask._version:
+    if getattr(mask, "_dasr_version", None) != ops.tensor_version(mask):
         return None
     return region
 
@@ -587,6 +592,41 @@ def upscale(tape, P, name, x, r, second):
     return x
 
 
+def encoder_forward(tape, P, cfg, x0, depth_mask):
+    """Encoder.forward (sftmd_arch.py:771-783) + RegionWiseAvgPooling: (e1, e5, st); e5 / st are None for a net without
+    depth blocks (the reference's ``isBaseline`` short-circuit, :774-775)."""
+    L = ops.ACT_LRELU
+    e1 = conv(tape, x0, _wn(tape, P, "encoder.layer1"), P["encoder.layer1.bias"], act=L)
+    e5 = st = None
+    # (the bf16 kernels want channel counts in multiples of 32: true for the reference's 32/64/128/L = 256 or 32 plan)
+    s2d_ok = all(P["encoder.layer%d.weight_v" % i].data.shape[0] % 32 == 0 and
+                 P["encoder.layer%d.weight_v" % i].data.shape[1] % 32 == 0 for i in (2, 3, 4, 5))
+    if len(cfg["which_ResBlk_depth"]) > 0 and tape.act_dtype == torch.bfloat16 and ENCODER_S2D and s2d_ok:
+        # mixed precision: the stride-2 layers as stride-1 bf16-MFMA convolutions of space-to-depth images / with a
+        # PixelShuffle(2) epilogue (csrc/s2d.hip); fp32 master weights, weight norm and its gradient as everywhere
+        def s2(name, x, act, valid_hw=None):
+            return conv(tape, space_to_depth2(tape, x, valid_hw), expand_s2(tape, _wn(tape, P, name)), P[name + ".bias"],
+                        act=act)
+        e2 = s2("encoder.layer2", e1, L)
+        e3 = s2("encoder.layer3", e2, L)
+        w4, b4 = expand_t2(tape, _wn(tape, P, "encoder.layer4", True), P["encoder.layer4.bias"])
+        e4 = conv(tape, e3, w4, b4, act=L, ps_r=2)
+        # sftmd_arch.py:748: ConvTranspose2d(3, stride=2, padding=1) WITHOUT output_padding -> (2H3-1) x (2W3-1); the
+        # PixelShuffle image e4 is 2H3 x 2W3, its last row / column do not exist in the reference: layer5 must see its
+        # zero padding there (and send no gradient back)
+        H3, W3 = e3.data.shape[1], e3.data.shape[2]
+        e5 = to_f32(tape, s2("encoder.layer5", e4, ops.ACT_NONE, (2 * H3 - 1, 2 * W3 - 1)))
+        st = region_pool(tape, e5, depth_mask)
+    elif len(cfg["which_ResBlk_depth"]) > 0:
+        e2 = conv(tape, e1, _wn(tape, P, "encoder.layer2"), P["encoder.layer2.bias"], stride=2, act=L)
+        e3 = conv(tape, e2, _wn(tape, P, "encoder.layer3"), P["encoder.layer3.bias"], stride=2, act=L)
+        e4 = conv(tape, e3, _wn(tape, P, "encoder.layer4", True), P["encoder.layer4.bias"], stride=2,
+                  transposed=True, act=L)
+        e5 = conv(tape, e4, _wn(tape, P, "encoder.layer5"), P["encoder.layer5.bias"], stride=2)
+        st = region_pool(tape, e5, depth_mask)
+    return e1, e5, st
+
+
 def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=None):
     """DepthNet.forward (sftmd_arch.py:912-950). ``inp`` [B,3,H,W], ``depth_map`` [B,1,h,w],
     ``depth_mask`` [B,K,h,w] are the caller's NCHW tensors; returns (out NCHW tensor, out Var).
@@ -597,30 +637,7 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=No
     x0 = Var(ops.nchw_to_nhwc(inp))
     dm = Var(depth_map.reshape(B, depth_map.shape[2], depth_map.shape[3], 1))   # [B,1,h,w] == [B,h,w,1]
     L = ops.ACT_LRELU
-    # Encoder.forward (sftmd_arch.py:771-783)
-    e1 = conv(tape, x0, _wn(tape, P, "encoder.layer1"), P["encoder.layer1.bias"], act=L)
-    st = None
-    # (the bf16 kernels want channel counts in multiples of 32: true for the reference's 32/64/128/L = 256 or 32 plan)
-    s2d_ok = all(P["encoder.layer%d.weight_v" % i].data.shape[0] % 32 == 0 and
-                 P["encoder.layer%d.weight_v" % i].data.shape[1] % 32 == 0 for i in (2, 3, 4, 5))
-    if len(cfg["which_ResBlk_depth"]) > 0 and tape.act_dtype == torch.bfloat16 and ENCODER_S2D and s2d_ok:
-        # mixed precision: the stride-2 layers as stride-1 bf16-MFMA convolutions of space-to-depth images / with a
-        # PixelShuffle(2) epilogue (csrc/s2d.hip); fp32 master weights, weight norm and its gradient as everywhere
-        def s2(name, x, act):
-            return conv(tape, space_to_depth2(tape, x), expand_s2(tape, _wn(tape, P, name)), P[name + ".bias"], act=act)
-        e2 = s2("encoder.layer2", e1, L)
-        e3 = s2("encoder.layer3", e2, L)
-        w4, b4 = expand_t2(tape, _wn(tape, P, "encoder.layer4", True), P["encoder.layer4.bias"])
-        e4 = conv(tape, e3, w4, b4, act=L, ps_r=2)
-        e5 = to_f32(tape, s2("encoder.layer5", e4, ops.ACT_NONE))
-        st = region_pool(tape, e5, depth_mask)
-    elif len(cfg["which_ResBlk_depth"]) > 0:
-        e2 = conv(tape, e1, _wn(tape, P, "encoder.layer2"), P["encoder.layer2.bias"], stride=2, act=L)
-        e3 = conv(tape, e2, _wn(tape, P, "encoder.layer3"), P["encoder.layer3.bias"], stride=2, act=L)
-        e4 = conv(tape, e3, _wn(tape, P, "encoder.layer4", True), P["encoder.layer4.bias"], stride=2,
-                  transposed=True, act=L)
-        e5 = conv(tape, e4, _wn(tape, P, "encoder.layer5"), P["encoder.layer5.bias"], stride=2)
-        st = region_pool(tape, e5, depth_mask)
+    e1, _e5, st = encoder_forward(tape, P, cfg, x0, depth_mask)
     mask_pack = MaskPack(depth_mask, region) if st is not None else None
     # head (:920).  Mixed precision: the encoder (0.8 % of the FLOPs, feeds the fp32 depth matrix) stays fp32; its first
     # feature map is rounded to bf16 here and everything up to conv_output's fp32 result runs on bf16 activations

@@ -135,21 +135,36 @@ def cast_to_f32(x):
 
 
 # ---- the encoder's stride-2 layers in stride-1 form (csrc/s2d.hip; bf16 path only) ----------------------------------
-def space_to_depth2(x):
-    """[B,H,W,C] fp32 or bf16 -> bf16 [B,ceil(H/2),ceil(W/2),4C], channel (2py+px)C + c = x[2i+py][2j+px][c]."""
+def tensor_version(t):
+    """torch's in-place edit counter of ``t``; tensors created under ``torch.inference_mode()`` do not track one
+    (reading it raises) and are reported as version -1: they are treated as immutable."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
+def space_to_depth2(x, valid_hw=None):
+    """[B,H,W,C] fp32 or bf16 -> bf16 [B,ceil(H/2),ceil(W/2),4C], channel (2py+px)C + c = x[2i+py][2j+px][c].
+    ``valid_hw`` = (Hv, Wv): rows / columns of x at or beyond them are read as zeros (the PixelShuffle image of the
+    encoder's transposed layer carries one row and one column the reference's layer does not have)."""
     B, H, W, C = x.shape
+    Hv, Wv = valid_hw if valid_hw is not None else (H, W)
     out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), dtype=BF16, device=x.device)
-    _call("dasr_space_to_depth2_bf16", _pa(x), 1 if x.dtype == BF16 else 0, _pa(out), B, H, W, C)
+    _call("dasr_space_to_depth2_bf16", _pa(x), 1 if x.dtype == BF16 else 0, _pa(out), B, H, W, C, Hv, Wv)
     return out
 
 
-def depth_to_space2_bwd(dy, x_shape, dtype, out=None):
-    """Adjoint of space_to_depth2: bf16 gradient [B,Hs,Ws,4C] -> gradient of x (``dtype``); ``out``: accumulate into it."""
+def depth_to_space2_bwd(dy, x_shape, dtype, out=None, valid_hw=None):
+    """Adjoint of space_to_depth2: bf16 gradient [B,Hs,Ws,4C] -> gradient of x (``dtype``), zero beyond ``valid_hw``;
+    ``out``: accumulate into it."""
     B, H, W, C = x_shape
+    Hv, Wv = valid_hw if valid_hw is not None else (H, W)
     acc = out is not None
     if out is None:
         out = torch.empty(tuple(x_shape), dtype=dtype, device=dy.device)
-    _call("dasr_depth_to_space2_bwd_bf16", _pa(dy), _pa(out), 1 if out.dtype == BF16 else 0, 1 if acc else 0, B, H, W, C)
+    _call("dasr_depth_to_space2_bwd_bf16", _pa(dy), _pa(out), 1 if out.dtype == BF16 else 0, 1 if acc else 0, B, H, W, C,
+          Hv, Wv)
     return out
 
 
@@ -350,7 +365,7 @@ def conv2d_wgrad_act(x, dy, y, w_shape, act, stride=1, pad=1, transposed=False, 
         return dw, db
     nbytes = lib.dasr_conv2d_wgrad_workspace(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, int(transposed))
     ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
-    fused = (Cin in (1, 3) and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not transposed)
+    fused = bool(lib.dasr_conv2d_wgrad_act_fused(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, int(transposed)))
     scratch = None if fused else torch.empty_like(y)
     dw = empty(w_shape, x)
     db = empty((Cout,), x) if want_bias else None

@@ -34,7 +34,7 @@ def depth_to_masks(depth, num_masks=10, fixed_range=False):
     edges = fixed_range_edges(num_masks, depth.device) if fixed_range else None
     planes, region = ops.depth_to_masks(depth, num_masks, edges, want_planes=True)
     planes._dasr_region = region
-    planes._dasr_version = planes._version     # the shortcut is dropped if the tensor is edited in place afterwards
+    planes._dasr_version = ops.tensor_version(planes)     # the shortcut is dropped if the tensor is edited in place afterwards
     return planes
 
 
@@ -58,5 +58,5 @@ def attach_region(masks):
     if int(flag.item()) != 0:
         return False
     masks._dasr_region = region
-    masks._dasr_version = masks._version
+    masks._dasr_version = ops.tensor_version(masks)
     return True

@@ -131,8 +131,11 @@ int dasr_conv2d_wgrad(const float* x, const float* dconv, float* dw_hwio, float*
                       int stride, int pad, int transposed, void* stream);
 
 /* Weight/bias gradient with the activation backward fused in: dconv = dy * act'(y) is formed on the fly where a
- * fused kernel exists (Cin == 1: SEAN.mlp_mask) and is materialised into dconv_scratch [B,Ho,Wo,Cout] otherwise
- * (dconv_scratch may be NULL only for shapes with a fused kernel).  For layers whose input needs no gradient. */
+ * fused kernel exists (Cin == 1: SEAN.mlp_mask; Cin == 3: the encoder's first layer) and is materialised into
+ * dconv_scratch [B,Ho,Wo,Cout] otherwise (dconv_scratch may be NULL only where dasr_conv2d_wgrad_act_fused() returns 1).
+ * For layers whose input needs no gradient. */
+int dasr_conv2d_wgrad_act_fused(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                                int transposed);
 int dasr_conv2d_wgrad_act(const float* x, const float* dy, const float* y, float* dw_hwio, float* dbias,
                           float* dconv_scratch, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin,
                           int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int transposed, int act,
@@ -308,18 +311,23 @@ int dasr_cast_bf16_to_f32(const unsigned short* src, float* dst, int accumulate,
 
 /* ---- the encoder's stride-2 layers on the bf16 stride-1 kernels (csrc/s2d.hip) -----------------------------------
  * Encoder (sftmd_arch.py:745-749, 771-783): nn.Conv2d(.., 3, stride=2, padding=1) x3 and
- * nn.ConvTranspose2d(.., 3, stride=2, padding=1, output_padding=1).  With bf16 activations they are expressed as
- * stride-1 3x3 convolutions (dasr_conv2d_*_bf16) of a space-to-depth image / with a PixelShuffle(2) epilogue:
- *   space_to_depth2:        y[b][i][j][(2py+px)C + c] = x[b][2i+py][2j+px][c], zero beyond an odd edge; x fp32 or bf16
- *   depth_to_space2_bwd:    the adjoint (gradient of the above), into an fp32 or bf16 tensor, optionally accumulating
+ * nn.ConvTranspose2d(.., 3, stride=2, padding=1) (no output_padding: (2H-1) x (2W-1) outputs).  With bf16 activations
+ * they are expressed as stride-1 3x3 convolutions (dasr_conv2d_*_bf16) of a space-to-depth image / with a PixelShuffle(2)
+ * epilogue (a 2H x 2W image whose last row and column the reference's layer does not have):
+ *   space_to_depth2:        y[b][i][j][(2py+px)C + c] = x[b][2i+py][2j+px][c] for 2i+py < Hv, 2j+px < Wv, zero beyond
+ *                           the VALID extents (Hv <= H, Wv <= W: H, W for a plain tensor; 2H'-1, 2W'-1 for the
+ *                           PixelShuffle image of the transposed layer); x fp32 or bf16
+ *   depth_to_space2_bwd:    the adjoint (gradient of the above: zero beyond the valid extents), into an fp32 or bf16
+ *                           tensor, optionally accumulating
  *   weight_expand_s2:       fp32 HWIO [3][3][Cin][Cout] -> the bf16 packed kernel [2][3][3][4Cin][Cout] of the stride-1 form
  *   weight_collapse_s2:     fp32 gradient of the expanded kernel [3][3][4Cin][Cout] -> [3][3][Cin][Cout]
  *   weight_expand_t2 / weight_collapse_t2: the same for the transposed convolution: [3][3][Cin][Cout] <-> Cin -> 4 Cout
  *                           (output channel 4co + 2a + b = phase (a, b) of the PixelShuffle), bias repeated / summed.
  * All C % 4 == 0. */
-int dasr_space_to_depth2_bf16(const void* x, int x_is_bf16, unsigned short* y, int B, int H, int W, int C, void* stream);
+int dasr_space_to_depth2_bf16(const void* x, int x_is_bf16, unsigned short* y, int B, int H, int W, int C, int Hv, int Wv,
+                              void* stream);
 int dasr_depth_to_space2_bwd_bf16(const unsigned short* dy, void* dx, int dx_is_bf16, int accumulate, int B, int H, int W,
-                                  int C, void* stream);
+                                  int C, int Hv, int Wv, void* stream);
 int dasr_weight_expand_s2_bf16(const float* w_hwio, unsigned short* out, int Cin, int Cout, void* stream);
 int dasr_weight_collapse_s2(const float* dw_expanded, float* dw_hwio, int Cin, int Cout, void* stream);
 int dasr_weight_expand_t2_bf16(const float* w_hwio, const float* bias, unsigned short* out, float* bias_out, int Cin,

@@ -67,11 +67,11 @@ ZERO_GRAD_KEYS = (".conv1.0.bias", ".conv2.0.bias")
 # Gates for check_depthnet_case, per case: (linear-functional gradient rel-L2 vs the reference's FLOAT64 run,
 # harness-loss gradient rel-L2 vs the reference's fp32 run).  Each is <= 10x the larger of the values measured on
 # the MI355X and on the kernel emulator (profiles/r02_gpu_tests.log keeps the printed dicts):
-#   x8_nb4      lin64 5.7e-4 (GPU and emulator): one ReLU decision at 6x8 flips in THIS implementation's rounding and
-#               moves norm1.alpha_beta by 16 %; loss 7.9e-5
+#   x8_nb4      lin64 1.65e-6 (GPU) / 1.62e-6 (emulator), loss 3.4e-7 / 4.2e-7  (an earlier tree flipped one ReLU decision
+#               at 6x8 and measured 5.7e-4; the gate that tolerated it is gone with the flip)
 #   x4_nb4      lin64 1.2e-6, loss 8.2e-7          x3_nb4      lin64 4.1e-7, loss 1.05e-5
 #   x2_nb4      lin64 5.4e-7, loss 1.3e-5          x8_nb5_odd  lin64 1.2e-6, loss 9.3e-7
-DEPTHNET_GATES = {"x8_nb4": (5e-3, 5e-4), "x4_nb4": (1e-5, 8e-6), "x3_nb4": (4e-6, 1e-4), "x2_nb4": (5e-6, 1.3e-4),
+DEPTHNET_GATES = {"x8_nb4": (1.6e-5, 4e-6), "x4_nb4": (1e-5, 8e-6), "x3_nb4": (4e-6, 1e-4), "x2_nb4": (5e-6, 1.3e-4),
                   "x8_nb5_odd": (1.2e-5, 9e-6)}
 
 
@@ -1149,7 +1149,8 @@ def check_bf16_conv_variants(device, seed=0):
 def check_bf16_encoder_s2d(device, seed=3):
     """The encoder's stride-2 Conv2d / ConvTranspose2d (sftmd_arch.py:745-749) in the stride-1 forms of csrc/s2d.hip
     (space-to-depth image + expanded kernel; expanded kernel + PixelShuffle(2) epilogue) against torch's own strided and
-    transposed convolutions of the same bf16-rounded operands: forward to 2^-8 of the largest value, and - through the
+    transposed convolutions (the latter WITHOUT output_padding, chained into the next stride-2 layer as the reference
+    chains layer4 into layer5) of the same bf16-rounded operands: forward to 2^-8 of the largest value, and - through the
     tape operators of graph.py - the input gradient (2^-7: two roundings) and the fp32 weight / bias gradients (2e-3: the
     LeakyReLU backward rounds dy * 0.2 to bf16 before the weight gradient sums it; measured 2e-4 .. 3e-4; a misplaced
     kernel slice would be an O(1) error).
@@ -1181,31 +1182,88 @@ def check_bf16_encoder_s2d(device, seed=3):
         assert xv.grad.dtype == xv.data.dtype and wv.grad.dtype == torch.float32
         assert e <= 2.0 ** -8 and e1 <= 2.0 ** -7 and e2 <= 2e-3 and e3 <= 2e-3, ("s2", cin, cout, H, W, e, e1, e2, e3)
         worst["s2 %d->%d %dx%d" % (cin, cout, H, W)] = (e, e1, e2, e3)
-    for (cin, cout, B, H, W) in [(128, 32, 1, 4, 5), (32, 64, 2, 6, 8)]:
+    # Encoder layers 4 -> 5 chained, as the reference has them (sftmd_arch.py:748-749): ConvTranspose2d(3, stride=2,
+    # padding=1) WITHOUT output_padding, i.e. (2H-1) x (2W-1) outputs, then LeakyReLU, then Conv2d(3, stride=2, padding=1).
+    # The PixelShuffle image of the stride-1 form is 2H x 2W: its first (2H-1) x (2W-1) pixels must be the reference's
+    # layer, and the next layer (space-to-depth with those VALID extents) must see zero padding in the extra row / column
+    # and send no gradient into it.  Reference on the same bf16-rounded operands, the layer-4 image rounded to bf16
+    # (straight-through) as the stride-1 path stores it.
+    for (cin, cout, B, H, W) in [(128, 32, 1, 4, 5), (32, 64, 2, 6, 8), (64, 32, 1, 3, 3)]:
         x = _bf(rn(B, cin, H, W))
         w = _bf(rn(cin, cout, 3, 3) * (1.0 / math.sqrt(9 * cin)))          # ConvTranspose2d: [Cin][Cout][kh][kw]
         bias = rn(cout) * 0.1
-        xt, wt, bt = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-        ref = F.leaky_relu(F.conv_transpose2d(xt, wt, bt, stride=2, padding=1, output_padding=1), 0.2)
-        dy = _bf(rn(*ref.shape))
-        gx, gw, gb = torch.autograd.grad(ref, (xt, wt, bt), dy)
+        w5 = _bf(rn(cout, cout, 3, 3) * (1.0 / math.sqrt(9 * cout)))
+        b5 = rn(cout) * 0.1
+        xt, wt, bt, w5t, b5t = [v.clone().requires_grad_(True) for v in (x, w, bias, w5, b5)]
+        ref4 = F.leaky_relu(F.conv_transpose2d(xt, wt, bt, stride=2, padding=1), 0.2)
+        assert tuple(ref4.shape[2:]) == (2 * H - 1, 2 * W - 1)
+        ref4r = ref4 + (_bf(ref4.detach()) - ref4.detach())
+        ref5 = F.conv2d(ref4r, w5t, b5t, stride=2, padding=1)
+        assert tuple(ref5.shape[2:]) == (H, W)
+        dy = _bf(rn(*ref5.shape))
+        gx, gw, gb, gw5, gb5 = torch.autograd.grad(ref5, (xt, wt, bt, w5t, b5t), dy)
         t = tp.Tape(True, BF16)
         xv = tp.Var(nhwc(x).to(device).to(BF16), True)
         # the packed form of a transposed kernel is HWIO of w[ci][co][kh][kw] (ops.weight_pack(transposed=True))
         wv = tp.Var(ops.pack_hwio(w.permute(2, 3, 0, 1).contiguous().to(device)), True)
         bv = tp.Var(bias.to(device), True)
+        w5v = tp.Var(ops.pack_hwio(w5.permute(2, 3, 1, 0).contiguous().to(device)), True)
+        b5v = tp.Var(b5.to(device), True)
         w4, b4 = graph.expand_t2(t, wv, bv)
-        y = graph.conv(t, xv, w4, b4, act=ops.ACT_LRELU, ps_r=2)
-        assert y.data.dtype == BF16 and tuple(y.data.shape) == tuple(nhwc(ref).shape), (y.data.shape, ref.shape)
-        e = (nchw(y.data.float().cpu()) - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
-        y.grad = nhwc(dy).to(device).to(BF16)
+        y4 = graph.conv(t, xv, w4, b4, act=ops.ACT_LRELU, ps_r=2)
+        assert y4.data.dtype == BF16 and tuple(y4.data.shape) == (B, 2 * H, 2 * W, cout), y4.data.shape
+        y5 = graph.conv(t, graph.space_to_depth2(t, y4, (2 * H - 1, 2 * W - 1)), graph.expand_s2(t, w5v), b5v)
+        assert tuple(y5.data.shape) == tuple(nhwc(ref5).shape), (y5.data.shape, ref5.shape)
+        y4c = nchw(y4.data.float().cpu())[:, :, :2 * H - 1, :2 * W - 1]
+        e4 = (y4c - ref4.detach()).abs().max().item() / ref4.detach().abs().max().item()
+        e = (nchw(y5.data.float().cpu()) - ref5.detach()).abs().max().item() / ref5.detach().abs().max().item()
+        y5.grad = nhwc(dy).to(device).to(BF16)
         t.backward()
         e1 = (nchw(xv.grad.float().cpu()) - gx).abs().max().item() / gx.abs().max().item()
-        e2 = rel_max(wv.grad.permute(2, 3, 0, 1), gw)
-        e3 = rel_max(bv.grad, gb)
-        assert e <= 2.0 ** -8 and e1 <= 2.0 ** -7 and e2 <= 2e-3 and e3 <= 2e-3, ("t2", cin, cout, H, W, e, e1, e2, e3)
-        worst["t2 %d->%d %dx%d" % (cin, cout, H, W)] = (e, e1, e2, e3)
+        e2 = max(rel_max(wv.grad.permute(2, 3, 0, 1), gw), rel_max(w5v.grad.permute(3, 2, 0, 1), gw5))
+        e3 = max(rel_max(bv.grad, gb), rel_max(b5v.grad, gb5))
+        # (measured on the emulator: e4 <= 2.9e-3, e <= 2.5e-3, e1 <= 2.9e-3, e2 <= 2.0e-3, e3 <= 2.5e-3; the extra row /
+        # column leaking into layer 5 - the output_padding=1 operator - is an O(1) error in the last output row and column)
+        assert e4 <= 2.0 ** -8 and e <= 2.0 ** -7 and e1 <= 2.0 ** -7 and e2 <= 6e-3 and e3 <= 6e-3, \
+            ("t2 -> s2", cin, cout, H, W, e4, e, e1, e2, e3)
+        worst["t2>s2 %d->%d %dx%d" % (cin, cout, H, W)] = (e4, e, e1, e2, e3)
     return {k: tuple(round(v, 7) for v in vs) for k, vs in worst.items()}
+
+
+def check_bf16_encoder_paths_agree(device):
+    """The two encoder implementations of the bf16 path - stride-1 bf16-MFMA forms (graph.ENCODER_S2D = True, the default)
+    and the fp32 gather kernels (False; pinned to the reference by check_encoder_geometry / the whole-net goldens) - must
+    compute the same function: e5 (layer5's output) and the region-pooled depth matrix st agree to bf16 rounding on even
+    and odd frame sizes.  (The output_padding=1 operator instead of the reference's transposed layer moved e5's last row
+    and column by 0.9 of the map's largest value and st by 0.81 in rel-L2.)"""
+    from dasr_amd import graph, tape as tp
+    out = {}
+    for (H, W) in ((16, 20), (17, 21), (12, 28)):
+        case = dict(name="enc", which=[0, 1], nb=4, scale=8, L=32, B=2, H=H, W=W)
+        net, cfg = build_net(case, device)
+        lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, 2, H, W, 8)]
+        P = {k: tp.Var(p.detach(), False, name=k) for k, p in net.named_parameters()}
+        res = {}
+        for s2d in (True, False):
+            graph.ENCODER_S2D = s2d
+            try:
+                t = tp.Tape(False, BF16)
+                x0 = tp.Var(ops.nchw_to_nhwc(lq))
+                e1, e5, st = graph.encoder_forward(t, P, cfg, x0, mk)
+            finally:
+                graph.ENCODER_S2D = True
+            res[s2d] = (e5.data.float().cpu(), st.data.float().cpu())
+        e5a, sta = res[True]
+        e5b, stb = res[False]
+        assert e5a.shape == e5b.shape and sta.shape == stb.shape
+        d5 = (e5a - e5b).abs().max().item() / e5b.abs().max().item()
+        edge = max((e5a[:, -1] - e5b[:, -1]).abs().max().item(), (e5a[:, :, -1] - e5b[:, :, -1]).abs().max().item()) / \
+            e5b.abs().max().item()
+        dst = ((sta - stb).pow(2).sum() / stb.pow(2).sum()).sqrt().item()
+        # measured (emulator): d5 <= 6e-3, st rel-L2 <= 5e-3
+        assert d5 <= 2e-2 and edge <= 2e-2 and dst <= 2e-2, ("encoder paths", H, W, d5, edge, dst)
+        out["%dx%d" % (H, W)] = (round(d5, 5), round(edge, 5), round(dst, 5))
+    return out
 
 
 def digest_cosine(named_grads, golden, prefix, skip=()):
@@ -1230,6 +1288,9 @@ def digest_cosine(named_grads, golden, prefix, skip=()):
 #   measured (emulator): x8_nb4 lin 0.106 loss 0.014 cos 0.99997;  x4_nb4 lin 0.224 loss 0.095 cos 0.9958
 # (x2_nb4 - four DGBs whose instance norms see 96 pixels - is too small a frame for 8-bit activations: 37 dB, not gated)
 BF16_GATES = {"x8_nb4": (0.32, 0.05, 0.999), "x4_nb4": (0.65, 0.28, 0.985)}
+# PSNR of the bf16 image against the reference's fp32 image of the same case (measured 48.3 / 45.7 dB with either encoder
+# implementation; the output_padding=1 encoder of round 2 sat at 41.7 / 37.3)
+BF16_PSNR_MIN = {"x8_nb4": 45.0, "x4_nb4": 43.0}
 
 
 def check_bf16_depthnet_case(case, device, dpsnr_tol=0.02):
@@ -1252,7 +1313,7 @@ def check_bf16_depthnet_case(case, device, dpsnr_tol=0.02):
     psnr_vs_ref = O.psnr_255(sr0.cpu(), ref)
     err = (sr0.cpu() - ref).abs().max().item()
     assert dpsnr <= dpsnr_tol, ("bf16 psnr", case["name"], dpsnr)
-    assert psnr_vs_ref >= 35.0, psnr_vs_ref          # measured 37.5 .. 48.5 dB at these frame sizes (8 significant bits)
+    assert psnr_vs_ref >= BF16_PSNR_MIN[case["name"]], psnr_vs_ref
     nograd = set(g["nograd"].tolist())
 
     def grads():

@@ -196,6 +196,11 @@ def test_bf16_encoder_s2d():
 
 
 @pytest.mark.gpu
+def test_bf16_encoder_paths_agree():
+    print(pc.check_bf16_encoder_paths_agree("cuda"))
+
+
+@pytest.mark.gpu
 def test_bf16_ops_vs_fp32_kernels():
     print(pc.check_bf16_ops_vs_fp32_kernels("cuda"))
 

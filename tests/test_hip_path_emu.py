@@ -111,6 +111,10 @@ def test_bf16_encoder_s2d(emu):
     print(pc.check_bf16_encoder_s2d("cpu"))
 
 
+def test_bf16_encoder_paths_agree(emu):
+    print(pc.check_bf16_encoder_paths_agree("cpu"))
+
+
 @pytest.mark.parametrize("name", ["x8_nb4", "x4_nb4"])
 def test_bf16_depthnet(emu, name):
     case = [c for c in DEPTHNET_CASES if c["name"] == name][0]
