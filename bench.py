@@ -20,11 +20,46 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
 
-import dasr_amd  # noqa: F401
-from dasr_amd import harness, networks, ops, prep, synth
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json config (default c2 = configs[1])")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: c2 16, c3 32, c4 16, c5 1)")
+    ap.add_argument("--mode", default="train", choices=("train", "infer"),
+                    help="train (default): fwd + losses + bwd + Adam; infer: eval + no_grad forward with folded weights "
+                         "(F_model_depthCond.test, F_model_depthCond.py:228-234) - never the driver's default")
+    ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"),
+                    help="cpu: the kernel emulator + gloo (tests of the launch / rank plumbing only; no timing claims)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b32", action="store_true", help="skip the forward-only batch-32 roofline pass")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="experiment: weight gradients on a third stream (graph.WGRAD_STREAM; measured slower at c2)")
+    ap.add_argument("--serial", action="store_true",
+                    help="profiling aid: depth branch on the main stream (no co-running kernels, so a rocprofv3 kernel trace "
+                         "shows isolated kernel durations); the reported value is then NOT the product configuration")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start torch.distributed.run as a CHILD process - one rank per
+    GPU, rendezvous on 127.0.0.1 - and relay its output and exit code.  Nothing in this process has touched the GPU at
+    this point (torch is not even imported), and nothing is exec'ed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
 
 LR_H, LR_W, SCALE, K_REGIONS = 128, 160, 8, 10
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
@@ -43,6 +78,8 @@ CONFIGS = {
     "c5": dict(scale=2, lr_hw=(1080, 1920), batch=1, dtype="f32", which=list(range(16)),
                workload="EndoScene x2 synthetic, batch=%d per GPU (BASELINE.json configs[4]: 8 over 8 GPUs), one 1080x1920 LR "
                         "frame, fp32, DepthNet nb=16 nf=64 L=256 K=10, DGBs 0..15; step = fwd + L1 + dynamic loss + bwd + Adam"),
+    "tiny": dict(scale=8, lr_hw=(16, 20), batch=1, dtype="f32", which=[0, 1], nb=4, latent=32,
+                 workload="plumbing check only (tests/test_bench_launch.py): x8, batch=%d per rank, 16x20 LR, DepthNet nb=4 L=32"),
     "c3": dict(scale=4, lr_hw=(256, 320), batch=32, dtype="bf16",
                workload="Kvasir x4 synthetic, batch=%d per GPU, bf16 activations + bf16-MFMA trunk convs (fp32 master "
                         "weights / statistics / accumulators), DepthNet nb=16 nf=64 L=256 K=10, LR 256x320 (BASELINE.json "
@@ -247,35 +284,43 @@ def cpu_baseline(frames=4, steps=3, max_warmup=5):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json config (default c2 = configs[1])")
-    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: c2 16, c3 32, c4 16, c5 1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-b32", action="store_true", help="skip the forward-only batch-32 roofline pass")
-    ap.add_argument("--wgrad-stream", action="store_true",
-                    help="experiment: weight gradients on a third stream (graph.WGRAD_STREAM; measured slower at c2)")
-    ap.add_argument("--serial", action="store_true",
-                    help="profiling aid: depth branch on the main stream (no co-running kernels, so a rocprofv3 kernel trace "
-                         "shows isolated kernel durations); the reported value is then NOT the product configuration")
-    args = ap.parse_args()
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    global torch, dist, harness, networks, ops, prep, synth
+    import torch
+    import torch.distributed as dist
+    cpu = args.device == "cpu"
+    if cpu:                                   # the CPU kernel emulator: test plumbing, never a measurement
+        sys.path.insert(0, ROOT)
+        import dasr_amd  # noqa: F401
+        from dasr_amd import build as _build
+        os.environ["DASR_HIPEMU_LIB"] = _build.build_emu()
+    import dasr_amd  # noqa: F401,F811
+    from dasr_amd import harness, networks, ops, prep, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)"
-                             % args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs the MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N does it "
+                         "itself)" % (args.gpus, world))
+    if cpu:
+        dev = torch.device("cpu")
+        torch.set_num_threads(max(1, host_cores() // max(1, world)))
+    else:
+        assert torch.cuda.is_available(), "bench.py needs the MI355X"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    sync = (lambda: None) if cpu else torch.cuda.synchronize
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
 
     cfg = CONFIGS[args.config]
@@ -292,6 +337,10 @@ def main():
     opt = {"network_G": dict(networks.X8_NETWORK_G, upscale=SCALE), "datasets": {"train": {"depthMaskNum": K_REGIONS}}}
     if "which" in cfg:
         opt["network_G"]["which_ResBlk_depth"] = list(cfg["which"])
+    if "nb" in cfg:
+        opt["network_G"]["nb"] = cfg["nb"]
+    if "latent" in cfg:
+        opt["network_G"]["depth_latent_ch"] = cfg["latent"]
     net = networks.define_G(opt)
     synth.closed_form_fill_(net.state_dict().items())
     net = net.to(dev)
@@ -304,16 +353,29 @@ def main():
     # the depth masks are derived from the depth map ON THE DEVICE (prep.depth_to_masks = getDepthMask, pinned to the
     # reference's function by tests/golden/depth_masks.npz): same planes as the host rule, plus the region bytes the
     # one-hot kernels read, so no rank ever reads a flag back from the GPU inside a step
-    mk = prep.depth_to_masks(dm, K_REGIONS)
-    assert torch.equal(mk.cpu(), mk_host), "device-side getDepthMask differs from the host rule"
+    if cpu:
+        mk = mk_host
+    else:
+        mk = prep.depth_to_masks(dm, K_REGIONS)
+        assert torch.equal(mk.cpu(), mk_host), "device-side getDepthMask differs from the host rule"
     del mk_host
     object.__setattr__(net, "_bench_inputs", (lq, dm, mk))
 
     timer = SeanTimer()
-    timer.install()
     timer_conv = ConvTimer()
-    if cfg["dtype"] == "bf16":
-        timer_conv.install()
+    if not cpu:
+        timer.install()
+        if cfg["dtype"] == "bf16":
+            timer_conv.install()
+    infer = args.mode == "infer"
+    if infer:
+        net.eval()
+
+    def step():
+        if infer:
+            with torch.no_grad():
+                return net(lq, dm, mk)
+        return trainer.optimize_parameters(lq, gt, dm, mk)
 
     def barrier():
         if world > 1:
@@ -325,20 +387,20 @@ def main():
 
     note("inputs resident; %d warm-up step(s)" % args.warmup)
     for i in range(args.warmup):
-        trainer.optimize_parameters(lq, gt, dm, mk)
-        torch.cuda.synchronize()
+        step()
+        sync()
         note("warm-up step %d done" % (i + 1))
-    torch.cuda.synchronize()
+    sync()
     barrier()
-    torch.cuda.synchronize()
-    timer.enabled = True
+    sync()
+    timer.enabled = not cpu
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.optimize_parameters(lq, gt, dm, mk)
+        step()
     host_enqueue = time.perf_counter() - t0       # the host has issued every launch of the timed steps (no sync in a step)
-    torch.cuda.synchronize()
+    sync()
     barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     note("host enqueue %.1f ms/step of %.1f ms/step" % (host_enqueue / args.steps * 1e3, elapsed / args.steps * 1e3))
     timer.enabled = False
@@ -346,7 +408,7 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
-    loss = float(trainer.log["l_all"])
+    loss = float(trainer.log["l_all"]) if not infer else float("nan")
 
     # Roofline of the dynamic-conv forward kernel.  In the timed steps the kernel shares the GPU with the side
     # stream's convolutions (graph.SIDE_STREAM), which stretches its duration and says nothing about the kernel, so
@@ -356,13 +418,14 @@ def main():
     timer.pairs = []
     from dasr_amd import graph as _graph
     _side = _graph.SIDE_STREAM
-    _graph.SIDE_STREAM = False
-    timer.enabled = True
-    trainer.optimize_parameters(lq, gt, dm, mk)
-    torch.cuda.synchronize()
-    timer.enabled = False
-    _graph.SIDE_STREAM = _side
     roof = None
+    if not cpu:
+        _graph.SIDE_STREAM = False
+        timer.enabled = True
+        step()
+        sync()
+        timer.enabled = False
+        _graph.SIDE_STREAM = _side
     s = timer.summary()
     if s is not None:
         avg_ms, avg_bytes, n = s
@@ -388,6 +451,9 @@ def main():
                 rec = json.load(open(pmc))
                 if rec.get("B") == B:          # counters were collected at this launch size
                     roof["traffic"] = int(rec.get("hbm_bytes_per_launch"))
+                    roof["traffic_source"] = ("profiles/sean_fwd_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                              "of this command at this launch size (tools/pmc_sean.py), NOT collected in "
+                                              "this run - counters cannot be read from inside the process")
             except Exception:
                 pass
 
@@ -396,9 +462,9 @@ def main():
     # (13 launches without / 13 with the residual read); both byte counts are reported: SURVEY §8d's (K mask floats as
     # delivered) and the kernel's true minimum (one region byte).
     roof32 = None
-    if rank == 0 and not args.no_b32 and args.config == "c2":
+    if rank == 0 and not cpu and not infer and not args.no_b32 and args.config == "c2":
         note("forward-only pass at batch 32 for roofline_b32")
-        del trainer
+        trainer = None
         net.zero_grad(set_to_none=True)
         torch.cuda.empty_cache()
         B32 = 32
@@ -445,24 +511,27 @@ def main():
                     pass
         del lq32, dm32, mk32
 
-    if cfg["dtype"] == "bf16":
+    if cfg["dtype"] == "bf16" and not cpu:
         roof = mfma_roofline(net, args, B, elapsed, timer_conv, args.config)
+    # rank 0 alone ran the batch-32 pass: the other ranks wait here, so nobody tears the process group down under it
+    barrier()
 
     if rank == 0:
         out = {
-            "metric": "LR frames/sec fwd+bwd at x%d (%dx%d LR)" % (SCALE, LR_H, LR_W),
+            "metric": ("LR frames/sec fwd+bwd at x%d (%dx%d LR)" if not infer else
+                       "LR frames/sec inference forward (eval + no_grad, folded weights) at x%d (%dx%d LR)") % (SCALE, LR_H, LR_W),
             "value": round(world * B * args.steps / elapsed, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": cfg["workload"] % B,
                        "global_batch": world * B, "lr_hw": [LR_H, LR_W], "scale": SCALE,
-                       "parallelism": "dp%d" % world},
-            "loss": round(loss, 6),
+                       "parallelism": "dp%d" % world, "mode": args.mode, "device": args.device},
+            "loss": round(loss, 6) if loss == loss else None,
             "roofline": roof,
             "roofline_b32": roof32,
         }
-        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
+        if world == 1 and not cpu and not infer and not args.no_cpu_baseline and args.config == "c2":
             note("GPU part done (%.1f ms/step); timing the CPU oracle baseline" % (1e3 * elapsed / args.steps))
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

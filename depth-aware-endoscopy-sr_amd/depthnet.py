@@ -145,6 +145,7 @@ class _DepthNetFunction(torch.autograd.Function):
         out = graph.depthnet_forward(tape, P, net.cfg, net._consts(inp.device), inp.detach().contiguous(),
                                      depth_map.detach().contiguous(), depth_mask.detach().contiguous(), region)
         ctx.tape, ctx.pvars, ctx.out = tape, pvars, out
+        ctx.hook = getattr(net, "_grad_bucket_hook", None)
         return out.data
 
     @staticmethod
@@ -153,6 +154,11 @@ class _DepthNetFunction(torch.autograd.Function):
         if tape is None:
             raise RuntimeError("DepthNet: backward called twice on the same forward")
         out.grad = dout.contiguous()
+        if ctx.hook is not None:
+            # data-parallel harness: parameter gradients completed so far, handed over at every bucket boundary of the
+            # tape so that their all-reduce overlaps the rest of the backward (harness.Trainer._on_grad_bucket)
+            hook = ctx.hook
+            tape.on_mark = lambda: hook(pvars)
         with _device_guard(dout):
             tape.backward()
         grads = tuple(v.grad for v in pvars)
@@ -160,7 +166,7 @@ class _DepthNetFunction(torch.autograd.Function):
         # `param.grad` instead of cloning each one (~300 extra copy kernels per step otherwise)
         for v in pvars:
             v.grad = None
-        ctx.tape = ctx.pvars = ctx.out = None
+        ctx.tape = ctx.pvars = ctx.out = ctx.hook = None
         return (None, None, None, None, None, None) + grads
 
 

@@ -682,10 +682,17 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=No
             return depth_block(tape, P, name, x, dm, mask_pack, st, consts, branch.get(i))
         return classic_block(tape, P, name, x)
 
+    # tape.mark(): gradient-bucket boundaries of the data-parallel harness (tape order = reverse backward order): the HR
+    # tail, the later and the earlier half of the LR blocks, then everything recorded before the trunk (encoder, head and
+    # the depth branch, whose backward is issued last)
     fea = fea_bef
+    tape.mark()
     for i in range(nb - 3):                       # :923 — block index nb-3 is constructed but never called
         fea = run_block(i, fea)
+        if i == (nb - 3) // 2 - 1:
+            tape.mark()
     fea = add(tape, fea, fea_bef)                 # :931
+    tape.mark()
     if scale == 8:
         fea = upscale(tape, P, "upscale1", fea, 2, True)
     fea = run_block(nb - 2, fea)

@@ -10,10 +10,12 @@ forward/backward is the HIP path.
 
 Data parallel: one process per GPU (torchrun), ``torch.distributed`` backend ``nccl`` (= RCCL over
 xGMI) on the GPU box, ``gloo`` in CPU tests.  The net itself is communication-free (instance norm is
-per-sample); per step there is ONE flat gradient all-reduce (14.8 M fp32 = 59 MB for the x8 net, plus
-the 10 loss weights), and the 2K numerator/denominator scalars of the dynamic loss are all-reduced so
-that the loss is the GLOBAL ratio the reference's default nn.DataParallel path computes on GPU0
-(SURVEY.md §8e).
+per-sample).  Per step: ONE small all-reduce of the packed loss scalars (K numerators | K denominators |
+sum|sr-hr|: the dynamic loss is then the GLOBAL ratio the reference's default nn.DataParallel path computes
+on GPU0, SURVEY.md §8e, and the logged L1 is the global-batch value), and the gradient all-reduce (14.8 M
+fp32 = 59 MB for the x8 net, plus the 10 loss weights) in FOUR flat buckets issued asynchronously from the
+backward tape as each bucket's gradients complete (HR tail, later LR blocks, earlier LR blocks, then encoder /
+head / depth branch / loss weights), waited for once before ``optimizer.step()``.
 """
 import math
 
@@ -79,17 +81,20 @@ def fused_losses(sr, hr, mask_list, trainable_weight, pixel_weight, dynamic_weig
     num, den, l1 = sums[:K], sums[K:2 * K].detach(), sums[2 * K]
     world = _world(group)
     l_pix = pixel_weight * l1 / sr.numel()
+    l_pix_global = l_pix.detach()
     if world > 1:
-        gden, gnum = den.clone(), num.detach().clone()
-        torch.distributed.all_reduce(gden, group=group)
-        torch.distributed.all_reduce(gnum, group=group)
+        # ONE collective for everything the step needs from the other ranks' losses: K numerators | K denominators | L1 sum
+        g = sums.detach().clone()
+        torch.distributed.all_reduce(g, group=group)
+        gnum, gden = g[:K], g[K:2 * K]
         local = num / gden * world
         per = gnum / gden + (local - local.detach())
+        l_pix_global = pixel_weight * g[2 * K] / (sr.numel() * world)
     else:
         per = num / den
     sm = F.softmax(trainable_weight, dim=0)
     l_dyn = (sm * per).sum() * dynamic_weight
-    return l_pix, l_dyn, per, sm
+    return l_pix, l_dyn, per, sm, l_pix_global
 
 
 class DynamicMaskLoss(torch.nn.Module):
@@ -104,7 +109,9 @@ class DynamicMaskLoss(torch.nn.Module):
         self.l_mask_w = weight
         self.trainable_weight = torch.nn.Parameter(torch.ones(num_regions))
 
-    def forward(self, sr, hr, mask_list, group=None):
+    def forward(self, sr, hr, mask_list, group=None, piggyback=None):
+        """``piggyback``: a detached scalar summed over the ranks in the same collective as the region sums (the
+        harness passes its local L1 value); its global sum is left in ``self.piggyback_sum``."""
         K = mask_list.shape[1]
         assert K == self.trainable_weight.numel(), "dynamic loss: %d trainable region weights but %d mask channels" % (self.trainable_weight.numel(), K)
         sm = F.softmax(self.trainable_weight, dim=0)
@@ -116,11 +123,14 @@ class DynamicMaskLoss(torch.nn.Module):
             dens.append(3.0 * m.sum())
         num, den = torch.stack(nums), torch.stack(dens)
         world = _world(group)
+        self.piggyback_sum = piggyback
         if world > 1:
-            gden = den.detach().clone()
-            gnum = num.detach().clone()
-            torch.distributed.all_reduce(gden, group=group)
-            torch.distributed.all_reduce(gnum, group=group)
+            parts = [num.detach(), den.detach()] + ([piggyback.detach().reshape(1)] if piggyback is not None else [])
+            g = torch.cat(parts)
+            torch.distributed.all_reduce(g, group=group)          # one collective: numerators | denominators | piggyback
+            gnum, gden = g[:K], g[K:2 * K]
+            if piggyback is not None:
+                self.piggyback_sum = g[2 * K]
             # value = global ratio; gradient: this rank's numerator over the global denominator, times world so
             # that the later gradient AVERAGE over ranks equals the gradient of the global loss
             local = num / gden * world
@@ -152,7 +162,23 @@ class Trainer:
         self.sched = dict(T_period=T_period, restarts=restarts, weights=restart_weights, eta_min=eta_min)
         self.step_count = 0
         self.log = {}
-        self._flat = None
+        self._buckets = []           # [(flat tensor, [parameter indices], async work)] of the step in flight
+        self._submitted = set()
+        self._pindex = {}
+        if self.world > 1:
+            self._enable_dp(self.world)
+
+    def _enable_dp(self, world):
+        """Switch the gradient exchange on for ``world`` ranks (the constructor does this when the group has more than one
+        rank; the single-GPU RCCL test calls it with a pretended world of 2 to exercise the bucketed path)."""
+        self.world = world
+        net = self.net
+        names = getattr(net, "_param_names", None)
+        if names is not None:        # the HIP DepthNet: its backward hands over completed gradients per tape bucket
+            byname = dict(net.named_parameters())
+            slot = {id(p): i for i, p in enumerate(self.params)}
+            self._pindex = {n: slot[id(byname[n])] for n in names if id(byname[n]) in slot}
+            object.__setattr__(net, "_grad_bucket_hook", self._on_grad_bucket)
 
     def update_learning_rate(self):
         self.step_count += 1                       # scheduler.step() comes first (codes/train.py:194)
@@ -161,24 +187,51 @@ class Trainer:
             g["lr"] = lr
         return lr
 
-    def _allreduce_grads(self):
-        """One flat all-reduce (sum, then / world).  Parameters that never receive a gradient
-        (the constructed-but-unused block ``depth-residual{nb-2}``) are skipped on
-        every rank alike, so the flat layout is identical everywhere."""
+    def _submit_bucket(self, idx, grads):
+        """Pack ``grads`` (of parameters ``idx``) with one concatenation and start their all-reduce asynchronously."""
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        work = torch.distributed.all_reduce(flat, group=self.group, async_op=True)
+        self._buckets.append((flat, idx, work))
+        self._submitted.update(idx)
+
+    def _on_grad_bucket(self, pvars):
+        """Called from the backward tape at each bucket boundary (tape.mark) with the net's parameter Vars: whatever has a
+        gradient by now and has not been sent yet is complete (every parameter is packed exactly once) and goes out.
+        Parameters that never receive a gradient (the constructed-but-unused block ``depth-residual{nb-2}``,
+        SURVEY.md §8a row 1) never show up, on every rank alike, so the bucket layouts are identical everywhere."""
+        idx, grads = [], []
+        cur = torch.cuda.current_stream() if pvars and pvars[0].data.is_cuda else None
+        for v in pvars:
+            i = self._pindex.get(v.name)
+            if i is None or v.grad is None or i in self._submitted:
+                continue
+            if cur is not None and v.grad_event is not None:   # produced on a side stream: order the pack after it
+                cur.wait_event(v.grad_event)
+            idx.append(i)
+            grads.append(v.grad)
+        self._submit_bucket(idx, grads)
+
+    def _finish_allreduce(self):
+        """The last bucket (everything the tape buckets did not cover, incl. the loss weights), then wait for all of them
+        and write the averaged gradients back with one multi-tensor copy per bucket."""
         if self.world <= 1:
             return
-        grads = [p.grad for p in self.params if p.grad is not None]
-        # pack with ONE concatenation kernel and unpack with one multi-tensor copy (a per-tensor copy loop is ~600 tiny
-        # launches per step around a 59 MB all-reduce)
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        torch.distributed.all_reduce(flat, group=self.group)
-        flat.div_(self.world)
-        views, off = [], 0
-        for g in grads:
-            k = g.numel()
-            views.append(flat[off:off + k].view_as(g))
-            off += k
-        torch._foreach_copy_(grads, views)
+        idx = [i for i, p in enumerate(self.params) if p.grad is not None and i not in self._submitted]
+        self._submit_bucket(idx, [self.params[i].grad for i in idx])
+        for flat, idx, work in self._buckets:
+            work.wait()
+            flat.div_(self.world)
+            grads = [self.params[i].grad for i in idx]
+            views, off = [], 0
+            for g in grads:
+                k = g.numel()
+                views.append(flat[off:off + k].view_as(g))
+                off += k
+            torch._foreach_copy_(grads, views)
+        self._buckets = []
+        self._submitted = set()
 
     def optimize_parameters(self, lq, gt, depth, masks):
         self.update_learning_rate()
@@ -191,18 +244,16 @@ class Trainer:
         fused = fused_losses(sr, gt, masks, self.dynamic_loss.trainable_weight, self.l_pix_w,
                              self.dynamic_loss.l_mask_w, grp)
         if fused is not None:
-            l_pix, l_dyn, per, sm = fused
+            l_pix, l_dyn, per, sm, l_pix_log = fused
         else:
             l_pix = self.l_pix_w * F.l1_loss(sr, gt)
-            per, weighted, l_dyn, sm = self.dynamic_loss(sr, gt, masks, grp)
+            per, weighted, l_dyn, sm = self.dynamic_loss(sr, gt, masks, grp, piggyback=l_pix.detach())
+            l_pix_log = self.dynamic_loss.piggyback_sum / self.world     # the global-batch value
         total = l_pix + l_dyn
+        self._buckets, self._submitted = [], set()
         total.backward()
-        self._allreduce_grads()
+        self._finish_allreduce()
         self.optimizer.step()
-        l_pix_log = l_pix.detach().clone()
-        if self.world > 1:                      # log the global-batch value (the gradient is already global)
-            torch.distributed.all_reduce(l_pix_log, group=self.group)
-            l_pix_log /= self.world
         self.log = {"l_all": l_pix_log + l_dyn.detach(), "l_pix": l_pix_log, "l_dynamic": l_dyn.detach()}
         return self.log
 

@@ -43,10 +43,19 @@ class Tape:
         self._stream = None
         self.side_streams = []
         self.fold_cache = None      # inference only: {param name: (versions, packed tensor)}, see graph._folded
+        self.marks = []             # node counts at which the forward plan called mark(): gradient-bucket boundaries
+        self.on_mark = None         # called during backward() each time the tape has unwound below a mark
 
     def record(self, fn):
         if self.enabled:
             self.nodes.append((fn, self._stream))
+
+    def mark(self):
+        """Bucket boundary for data-parallel training: every parameter whose packing node was recorded AFTER this point
+        has its gradient complete once backward() has unwound to here (harness.Trainer starts that bucket's all-reduce
+        from ``on_mark`` while the rest of the backward is still being issued)."""
+        if self.enabled:
+            self.marks.append(len(self.nodes))
 
     def on_stream(self, stream):
         tape = self
@@ -76,6 +85,10 @@ class Tape:
             else:
                 with torch.cuda.stream(stream):
                     fn()
+            while self.marks and len(self.nodes) <= self.marks[-1]:
+                self.marks.pop()
+                if self.on_mark is not None:
+                    self.on_mark()
         for s in self.side_streams:          # parameter gradients produced on side streams are complete
             torch.cuda.current_stream().wait_stream(s)
 

@@ -108,7 +108,14 @@ def _hip_step(emu_lib, rank, world, group):
     tr = harness.Trainer(net, 10, group=group)
     per = c["B"] // world
     lq, gt, dm, mk = synth.closed_form_batch(rank * per, per, c["H"], c["W"], c["scale"])
+    sizes = []
+    orig = tr._submit_bucket
+    tr._submit_bucket = lambda idx, grads: (sizes.append(len(idx)), orig(idx, grads))[1]
     log = tr.optimize_parameters(lq, gt, dm, mk)
+    if world > 1:        # the tape's bucket boundaries fired inside the backward; the last bucket carries the loss weights
+        assert len(sizes) >= 3 and sizes[0] > 0 and sizes[-1] > 0, sizes
+    else:
+        assert sizes == [], sizes
     grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
     grads["loss_w"] = tr.dynamic_loss.trainable_weight.grad.detach().clone()
     return float(log["l_all"]), grads

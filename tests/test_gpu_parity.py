@@ -98,13 +98,15 @@ def test_checkpoint_interop(tmp_path):
 
 
 @pytest.mark.gpu
-def test_rccl_flat_allreduce_single_rank():
+def test_rccl_bucketed_allreduce_single_rank():
     """The N > 1 code path on real device memory: RCCL (backend "nccl") initialises on this box, and the trainer's
-    flat gradient pack -> all_reduce -> / world -> unpack round-trips.  A one-rank group cannot show the sum, so the
-    trainer is told the world is 2: every gradient must come back exactly halved."""
+    bucketed gradient exchange (tape marks -> pack -> async all_reduce per bucket -> wait -> / world -> unpack) round-trips
+    through the HIP DepthNet's own backward.  A one-rank group cannot show the sum, so the trainer is told the world is 2:
+    every gradient must come back exactly halved, the buckets must be the four the tape defines, and a c4-shaped step
+    (x8, 16 frames, bf16) must not get measurably slower with the exchange on (HIP events; printed)."""
     import os
     import torch.distributed as dist
-    from dasr_amd import harness
+    from dasr_amd import harness, networks, prep
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29571")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -113,19 +115,62 @@ def test_rccl_flat_allreduce_single_rank():
         dist.all_reduce(t)
         dist.barrier()
         assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
-        case = dict(name="rccl", scale=2, which=[0, 1], L=16, nb=4, B=1, H=8, W=12)
+        case = dict(name="rccl", scale=8, which=[0, 1, 2, 3], L=16, nb=6, B=1, H=8, W=12)
         net, cfg = pc.build_net(case, "cuda")
         tr = harness.Trainer(net, group=dist.group.WORLD)
-        lq, gt, dm, mk = [x.cuda() for x in pc.synth.seeded_batch(0, 1, 8, 12, 2)]
+        lq, gt, dm, mk = [x.cuda() for x in pc.synth.seeded_batch(0, 1, 8, 12, 8)]
         sr = net(lq, dm, mk)
         (sr * sr).mean().backward()
         before = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
-        tr.world = 2
-        tr._allreduce_grads()
+        net.zero_grad(set_to_none=True)
+        tr._enable_dp(2)
+        sizes = []
+        orig = tr._submit_bucket
+        tr._submit_bucket = lambda idx, grads: (sizes.append(len(idx)), orig(idx, grads))[1]
+        sr = net(lq, dm, mk)
+        (sr * sr).mean().backward()
+        assert len(sizes) == 3 and all(n > 0 for n in sizes), sizes      # the three tape marks fired inside backward
+        tr._finish_allreduce()
         torch.cuda.synchronize()
+        assert len(sizes) == 4 and sizes[3] > 0, sizes
+        n = 0
         for k, p in net.named_parameters():
             if p.grad is not None:
                 assert torch.equal(p.grad, before[k] / 2), k
+                n += 1
+        assert n == sum(sizes), (n, sizes)
+        del net, tr
+        # c4's per-GPU step with and without the exchange
+        opt = {"network_G": dict(networks.X8_NETWORK_G), "datasets": {"train": {"depthMaskNum": 10}}}
+        net = networks.define_G(opt)
+        pc.synth.closed_form_fill_(net.state_dict().items())
+        net = net.cuda().set_compute_dtype(torch.bfloat16)
+        lq, gt, dm, _ = pc.synth.seeded_batch(0, 16, 128, 160, 8)
+        lq, gt, dm = lq.cuda(), gt.cuda(), dm.cuda()
+        mk = prep.depth_to_masks(dm, 10)
+        ms = {}
+        for world in (1, 2):
+            tr = harness.Trainer(net)
+            tr.group = dist.group.WORLD
+            if world > 1:
+                tr._enable_dp(world)
+            else:
+                tr.world = 1
+                object.__setattr__(net, "_grad_bucket_hook", None)
+            for _ in range(2):
+                tr.optimize_parameters(lq, gt, dm, mk)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                tr.optimize_parameters(lq, gt, dm, mk)
+            e1.record()
+            torch.cuda.synchronize()
+            ms[world] = e0.elapsed_time(e1) / 4
+            assert bool(torch.isfinite(tr.log["l_all"]))
+        print("c4 step: %.2f ms without, %.2f ms with the bucketed exchange (one-rank RCCL group, world pretended 2)"
+              % (ms[1], ms[2]))
+        assert ms[2] - ms[1] < 3.0, ms
     finally:
         dist.destroy_process_group()
 
