@@ -45,7 +45,8 @@ def build_hip(force=False, verbose=True, extra_flags=()):
     objdir = os.path.join(PKG_DIR, "build")
     os.makedirs(objdir, exist_ok=True)
     cc = _hipcc()
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    # DASR_HIPCC_EXTRA: extra compiler flags for experiments (e.g. -DDASR_V2_DEBUG); never set for the product build
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + os.environ.get("DASR_HIPCC_EXTRA", "").split()
     procs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")

@@ -470,11 +470,15 @@ static int launch_conv_bf16(ConvBf16Args& a, void* stream) {
 
 int conv_bf16_fwd(const ConvGeom& g, const bf16_t* x, const bf16_t* w, const float* bias, const bf16_t* residual,
                   bf16_t* y, int act, int ps_r, void* stream) {
+    if (conv_bf16_v2_supported(g.H, g.W, g.Cin, g.Cout, ps_r, residual != nullptr, false))
+        return conv_bf16_v2_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
     ConvBf16Args a{x, w, bias, residual, y, g.B, g.H, g.W, g.Cin, g.Cout, act, ps_r, 0};
     return launch_conv_bf16<0>(a, stream);
 }
 // dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * W[tap][ci][co]: a 3x3 conv of dconv (channels Cout) to Cin
 int conv_bf16_dgrad(const ConvGeom& g, const bf16_t* dconv, const bf16_t* w, bf16_t* dx, int accumulate, void* stream) {
+    if (conv_bf16_v2_supported(g.H, g.W, g.Cout, g.Cin, 1, false, accumulate != 0))
+        return conv_bf16_v2_dgrad(g, dconv, w, dx, accumulate, stream);
     ConvBf16Args a{dconv, w, nullptr, nullptr, dx, g.B, g.H, g.W, g.Cout, g.Cin, DASR_ACT_NONE, 1, accumulate};
     return launch_conv_bf16<1>(a, stream);
 }

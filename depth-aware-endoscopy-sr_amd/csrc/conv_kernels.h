@@ -79,6 +79,12 @@ int conv_bf16_dgrad(const ConvGeom& g, const bf16_t* dconv, const bf16_t* w, bf1
 size_t conv_bf16_wgrad_workspace(const ConvGeom& g);
 int conv_bf16_wgrad(const ConvGeom& g, const bf16_t* x, const bf16_t* dconv, float* dw, float* dbias, void* workspace,
                     void* stream);
+// conv_bf16_v2.hip (persistent LDS-DMA kernel for forward / dgrad; Cin % 32 == 0, Cout % 64 == 0 in the KERNEL's terms -
+// reduction / produced channels -, PixelShuffle 1 or 2); conv_bf16_fwd / conv_bf16_dgrad dispatch to it
+bool conv_bf16_v2_supported(int H, int W, int Cin, int Cout, int ps_r, bool has_residual, bool accumulate);
+int conv_bf16_v2_fwd(const ConvGeom& g, const bf16_t* x, const bf16_t* w, const float* bias, const bf16_t* residual,
+                     bf16_t* y, int act, int ps_r, void* stream);
+int conv_bf16_v2_dgrad(const ConvGeom& g, const bf16_t* dconv, const bf16_t* w, bf16_t* dx, int accumulate, void* stream);
 // the same kernels as their fp32 namesakes, instantiated for bf16 activations
 int conv_epilogue_bwd_bf16(const ConvGeom& g, const bf16_t* dy, const bf16_t* y, bf16_t* dconv, int act, int ps_r,
                            void* stream);

@@ -16,6 +16,16 @@
 #define DASR_MUL24(a, b) ((a) * (b))
 #define DASR_SCHED_BARRIER() ((void)0)
 #define DASR_WAVE_SYNC() hipemu::wave_barrier()
+// LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane from a per-lane global address to wave-uniform LDS base + 16 * lane.
+// The emulator copies synchronously, so the counted waits are no-ops there and the barrier is the block barrier.
+typedef char* dasr_lds_addr_t;
+#define DASR_LDS_ADDR(p) ((char*)(p))
+#define DASR_GLDS16(gsrc, lds_base) memcpy((lds_base) + 16 * hipemu::lane_id(), (const void*)(gsrc), 16)
+#define DASR_WAIT_VM(n) ((void)0)
+#define DASR_RAW_BARRIER() hipemu::block_barrier()
+#define DASR_SETPRIO(n) ((void)0)
+#define DASR_SCHED_GROUP(mask, n) ((void)0)
+#define DASR_DEVICE_CONST static const
 #else
 #include <hip/hip_runtime.h>
 #define DASR_LAUNCH(kernel, grid, block, shmem, stream, ...) \
@@ -32,6 +42,25 @@
 #define DASR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// LDS-DMA, hidden from the compiler on purpose (cdna_hip_programming.md, "Pipelining across barriers"): behind the
+// builtin hipcc waits vmcnt(0) before the next LDS read that may alias, which serialises every prefetch; in inline asm
+// the transfer is invisible to its counters and the kernel counts it by hand (DASR_WAIT_VM) - every wave must then issue
+// the SAME number of vector-memory operations between two waits (EXEC full, no skipped pieces).  M0 carries the LDS
+// base and is compiler-reserved: saved and restored inside the statement.
+typedef unsigned dasr_lds_addr_t;
+#define DASR_LDS_ADDR(p) ((unsigned)(size_t)(__attribute__((address_space(3))) char*)(p))
+__device__ __forceinline__ void dasr_glds16(const void* gsrc, unsigned lds_base_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base_uniform) : "memory");
+}
+#define DASR_GLDS16(gsrc, lds_base) dasr_glds16((const void*)(gsrc), __builtin_amdgcn_readfirstlane(lds_base))
+#define DASR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define DASR_RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define DASR_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+// scheduling hint: the next n instructions of the masked kind (0x8 MFMA, 0x100 LDS read, 0x2 VALU) go here, in this order
+#define DASR_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+#define DASR_DEVICE_CONST __device__ const
 #endif
 
 #include "../../include/dasr.h"

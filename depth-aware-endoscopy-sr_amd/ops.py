@@ -135,6 +135,16 @@ def cast_to_f32(x):
 
 
 # ---- the encoder's stride-2 layers in stride-1 form (csrc/s2d.hip; bf16 path only) ----------------------------------
+def set_conv_bf16_impl(impl):
+    """0 (default): the persistent LDS-DMA kernel runs the bf16 trunk forward / dgrad where it applies; 1: the first
+    (register-staged) kernel everywhere - for A/B measurements and tests."""
+    _call("dasr_set_conv_bf16_impl", int(impl))
+
+
+def conv_bf16_v2_launches():
+    return int(_lib.get().dasr_conv_bf16_v2_launches())
+
+
 def tensor_version(t):
     """torch's in-place edit counter of ``t``; tensors created under ``torch.inference_mode()`` do not track one
     (reading it raises) and are reported as version -1: they are treated as immutable."""

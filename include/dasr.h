@@ -274,6 +274,15 @@ int dasr_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, const 
                          int act, int ps_r, void* stream);
 int dasr_conv2d_epilogue_bwd_bf16(const unsigned short* dy, const unsigned short* y, unsigned short* dconv, int B, int Ho,
                                   int Wo, int Cout, int act, int ps_r, void* stream);
+/* Which kernel runs the trunk's forward / dgrad: 0 (default) = the persistent LDS-DMA kernel (csrc/conv_bf16_v2.hip) where
+ * it applies (Cin % 32 == 0, Cout % 64 == 0, PixelShuffle 1 or 2), 1 = the first, register-staged kernel everywhere,
+ * 2 = the persistent kernel with one workgroup per XCD (tests: long per-workgroup item lists on small shapes);
+ * + 16 = force its 8-row / 4-wave form, + 32 = its 16-row / 8-wave form (default: by problem size).
+ * For A/B measurements and tests; process-wide, not thread-safe against concurrent launches.
+ * dasr_conv_bf16_v2_launches(): how many times the persistent kernel has been launched by this process. */
+int dasr_set_conv_bf16_impl(int impl);
+int dasr_get_conv_bf16_impl(void);
+int dasr_conv_bf16_v2_launches(void);
 /* trunk: dconv bf16, w packed bf16; output conv: dconv f32, w packed f32.  dx bf16. */
 int dasr_conv2d_dgrad_bf16(const void* dconv, const void* w, unsigned short* dx, int accumulate, int B, int H, int W, int Cin,
                            int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int transposed, void* stream);

@@ -1087,20 +1087,34 @@ def _bf(x):
     return x.to(BF16).to(torch.float32)
 
 
-def check_bf16_conv_variants(device, seed=0):
+def check_bf16_conv_variants(device, seed=0, impl=0):
     """dasr_conv2d_{fwd,dgrad,wgrad}_bf16 (v_mfma_f32_32x32x16_bf16 kernels, transposed LDS reads in the weight gradient)
     against torch's fp32 convolution of the SAME bf16-rounded operands: the only differences left are the fp32
     accumulation order and the final rounding of the bf16 outputs (half an ulp = 2^-9 relative), so the gates are
     max |err| <= 2^-8 * max|ref| for bf16 outputs and 1e-5 relative for the fp32 weight / bias gradients.
     Covers every (MT, NTW) block of the weight gradient, both N-tile widths of the forward, ragged tile rows /
-    columns, fused bias / ReLU / LeakyReLU / residual / PixelShuffle(2, 3) epilogues and the accumulating dgrad."""
+    columns, fused bias / ReLU / LeakyReLU / residual / PixelShuffle(2, 3) epilogues and the accumulating dgrad.
+    ``impl`` (ops.set_conv_bf16_impl): 0 = the persistent LDS-DMA kernel where it applies (1, 3 and 4 channel chunks, one
+    to three channel slices per pixel tile, both tile widths), 2 = the same with ONE workgroup per XCD, so that every
+    workgroup walks a list of items (cross-item prefetch, accumulator re-initialisation, slice changes), 1 = the first
+    kernel everywhere."""
+    ops.set_conv_bf16_impl(impl)
+    try:
+        return _check_bf16_conv_variants(device, seed, impl)
+    finally:
+        ops.set_conv_bf16_impl(0)
+
+
+def _check_bf16_conv_variants(device, seed, impl):
     gen = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=gen)
     cases = [  # cin, cout, act, ps_r, residual, B, H, W
         (32, 32, 1, 1, True, 1, 8, 32), (64, 64, 0, 1, False, 2, 9, 33), (32, 64, 2, 1, False, 1, 16, 64),
         (64, 32, 2, 1, False, 1, 7, 40), (128, 128, 0, 1, False, 1, 8, 32), (64, 256, 2, 2, False, 1, 6, 32),
         (32, 128, 2, 2, False, 1, 10, 35), (64, 288, 2, 3, False, 1, 5, 32), (64, 64, 1, 1, True, 1, 8, 30),
+        (96, 192, 1, 1, False, 2, 19, 70), (128, 256, 2, 1, True, 1, 17, 45), (256, 64, 0, 1, False, 3, 9, 66),
     ]
+    n_v2 = ops.conv_bf16_v2_launches()
     if device != "cpu":        # BASELINE.json configs[2] frame size: many tile rounds, both N slices, 8 XCD-ordered waves of blocks
         cases += [(64, 64, 0, 1, False, 2, 256, 320), (128, 128, 0, 1, False, 1, 256, 320), (32, 128, 2, 2, False, 1, 512, 640)]
     worst = {}
@@ -1143,6 +1157,8 @@ def check_bf16_conv_variants(device, seed=0):
         e4 = rel_max(db, gb)
         assert e3 <= 1e-5 and e4 <= 1e-5, ("wgrad", cin, cout, e3, e4)
         worst[(cin, cout, ps, H)] = (e, e1, e2, e3, e4)
+    n_v2 = ops.conv_bf16_v2_launches() - n_v2
+    assert (n_v2 == 0) if (impl & 3) == 1 else (n_v2 >= 2 * len(cases) - 6), (impl, n_v2)   # the persistent kernel really ran
     return {"%d->%d ps%d H%d" % k: tuple(round(v, 7) for v in vs) for k, vs in worst.items()}
 
 

@@ -136,7 +136,9 @@ def test_rccl_bucketed_allreduce_single_rank():
         n = 0
         for k, p in net.named_parameters():
             if p.grad is not None:
-                assert torch.equal(p.grad, before[k] / 2), k
+                # (two backward passes differ in the last bits: the weight-gradient slabs are summed with atomics)
+                d = (p.grad - before[k] / 2).abs().max().item()
+                assert d <= 1e-4 * before[k].abs().max().item() + 1e-9, (k, d)
                 n += 1
         assert n == sum(sizes), (n, sizes)
         del net, tr
@@ -148,8 +150,8 @@ def test_rccl_bucketed_allreduce_single_rank():
         lq, gt, dm, _ = pc.synth.seeded_batch(0, 16, 128, 160, 8)
         lq, gt, dm = lq.cuda(), gt.cuda(), dm.cuda()
         mk = prep.depth_to_masks(dm, 10)
-        ms = {}
-        for world in (1, 2):
+        ms = {1: [], 2: []}
+        for world in (1, 2, 1, 2):               # interleaved: allocator growth and clocks hit both arms alike
             tr = harness.Trainer(net)
             tr.group = dist.group.WORLD
             if world > 1:
@@ -157,20 +159,20 @@ def test_rccl_bucketed_allreduce_single_rank():
             else:
                 tr.world = 1
                 object.__setattr__(net, "_grad_bucket_hook", None)
-            for _ in range(2):
+            for _ in range(3):
                 tr.optimize_parameters(lq, gt, dm, mk)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(4):
+            for _ in range(5):
                 tr.optimize_parameters(lq, gt, dm, mk)
             e1.record()
             torch.cuda.synchronize()
-            ms[world] = e0.elapsed_time(e1) / 4
+            ms[world].append(e0.elapsed_time(e1) / 5)
             assert bool(torch.isfinite(tr.log["l_all"]))
-        print("c4 step: %.2f ms without, %.2f ms with the bucketed exchange (one-rank RCCL group, world pretended 2)"
-              % (ms[1], ms[2]))
-        assert ms[2] - ms[1] < 3.0, ms
+        print("c4 step: %s ms without, %s ms with the bucketed exchange (one-rank RCCL group, world pretended 2)"
+              % (["%.2f" % v for v in ms[1]], ["%.2f" % v for v in ms[2]]))
+        assert min(ms[2]) - min(ms[1]) < 1.5, ms          # measured +0.3 ms (tools/time_exchange.py steps)
     finally:
         dist.destroy_process_group()
 
@@ -231,8 +233,10 @@ def test_region_shortcut_invalidation():
 
 
 @pytest.mark.gpu
-def test_bf16_conv_variants():
-    print(pc.check_bf16_conv_variants("cuda"))
+@pytest.mark.parametrize("impl", [0, 16, 32, 2 + 16, 2 + 32, 1],
+                         ids=["persistent", "4wave", "8wave", "4wave_1wg_per_xcd", "8wave_1wg_per_xcd", "first_kernel"])
+def test_bf16_conv_variants(impl):
+    print(pc.check_bf16_conv_variants("cuda", impl=impl))
 
 
 @pytest.mark.gpu

@@ -103,8 +103,9 @@ def test_region_shortcut_invalidation(emu):
     print(pc.check_region_shortcut_invalidation("cpu"))
 
 
-def test_bf16_conv_variants(emu):
-    print(pc.check_bf16_conv_variants("cpu"))
+@pytest.mark.parametrize("impl", [0, 2 + 16, 2 + 32, 1], ids=["persistent", "4wave_1wg_per_xcd", "8wave_1wg_per_xcd", "first_kernel"])
+def test_bf16_conv_variants(emu, impl):
+    print(pc.check_bf16_conv_variants("cpu", impl=impl))
 
 
 def test_bf16_encoder_s2d(emu):

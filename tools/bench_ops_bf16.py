@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--hw", default="256x320")
+    ap.add_argument("--impl", default="1,16,32", help="conv3x3 forward / dgrad kernels to compare (ops.set_conv_bf16_impl "
+                    "codes, comma separated): 1 first kernel, 0 persistent (auto), 16 its 4-wave form, 32 its 8-wave form")
     a = ap.parse_args()
     dev = torch.device("cuda")
     H, W = (int(v) for v in a.hw.split("x"))
@@ -81,11 +83,20 @@ def main():
             y = ops.conv2d_fwd(x, wt, bias)
             fl = 2.0 * 9 * ci * co * B * h * w
             nb = B * h * w * (ci + co) * 2
-            us = timeit(lambda: ops.conv2d_fwd(x, wt, bias), a.iters)
-            us_d = timeit(lambda: ops.conv2d_dgrad(y, wt, x.shape, out_dtype=BF), a.iters)
             us_w = timeit(lambda: ops.conv2d_wgrad(x, y, tuple(wt.shape[1:])), a.iters)
-            print("conv3x3 bf16 %3dx%3d %3d->%3d fwd %8.1f us %6.1f TF %5.2f TB/s | dgrad %8.1f us %6.1f TF | wgrad %8.1f us %6.1f TF"
-                  % (h, w, ci, co, us, fl / us / 1e6, nb / us / 1e6, us_d, fl / us_d / 1e6, us_w, fl / us_w / 1e6))
+            impls = tuple(int(v) for v in a.impl.split(","))
+            res = {i: [] for i in impls}
+            for rnd in range(3):                  # interleaved rounds in one process (cdna_hip_programming.md rule 24)
+                for i in impls:
+                    ops.set_conv_bf16_impl(i)
+                    res[i].append((timeit(lambda: ops.conv2d_fwd(x, wt, bias), a.iters),
+                                   timeit(lambda: ops.conv2d_dgrad(y, wt, x.shape, out_dtype=BF), a.iters)))
+            ops.set_conv_bf16_impl(0)
+            for i in impls:
+                us = sorted(r[0] for r in res[i])[1]
+                us_d = sorted(r[1] for r in res[i])[1]
+                print("conv3x3 bf16 %3dx%3d %3d->%3d impl %2d fwd %8.1f us %6.1f TF %5.2f TB/s | dgrad %8.1f us %6.1f TF | wgrad %8.1f us %6.1f TF"
+                      % (h, w, ci, co, i, us, fl / us / 1e6, nb / us / 1e6, us_d, fl / us_d / 1e6, us_w, fl / us_w / 1e6))
             del x, y
     if not a.only or "conv9" in a.only:
         x = rb(B, 4 * H, 4 * W, 32)
