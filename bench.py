@@ -33,6 +33,8 @@ def parse_args(argv=None):
                          "(F_model_depthCond.test, F_model_depthCond.py:228-234) - never the driver's default")
     ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"),
                     help="cpu: the kernel emulator + gloo (tests of the launch / rank plumbing only; no timing claims)")
+    ap.add_argument("--no-split", action="store_true",
+                    help="A/B: fp32 path without the split-bf16 convolutions (graph.SPLIT_BF16 = False: exact-fp32 MFMA kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the forward-only batch-32 roofline pass")
     ap.add_argument("--wgrad-stream", action="store_true",
@@ -327,6 +329,9 @@ def main():
     if args.wgrad_stream:
         from dasr_amd import graph as _graph_mod2
         _graph_mod2.WGRAD_STREAM = True
+    if args.no_split:
+        from dasr_amd import graph as _graph_mod3
+        _graph_mod3.SPLIT_BF16 = False
     if args.serial:
         from dasr_amd import graph as _graph_mod
         _graph_mod.SIDE_STREAM = False

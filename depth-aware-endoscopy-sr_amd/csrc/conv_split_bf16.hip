@@ -1,0 +1,350 @@
+// conv_split_bf16.hip — fp32 3x3 / stride 1 / pad 1 convolutions (forward and dgrad) at fp32 accuracy on the BF16 matrix
+// cores: "split bf16".  For the fp32 path's plain trunk convolutions (bias only): mlp_gamma_o | mlp_beta_o
+// (normalization.py:41-42,73-74: 128 -> 128, 41 % of the x8 step) and the DGB convolutions (sftmd_arch.py:811-820: 64 -> 64).
+//
+// Why.  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate and the fp32 kernels of conv_mfma.hip already sit at 81-85 % of
+// that peak: the fp32 step has no other lever left.  An fp32 value is the exact sum of three bf16 pieces
+// (x = x0 + x1 + x2, x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 3 x 8 significant bits + signs >= 24), a
+// product of two bf16 values is exact in fp32, and
+//     x * w = x0 w0 + (x0 w1 + x1 w0) + (x0 w2 + x1 w1 + x2 w0) + O(2^-26 |x w|)
+// so SIX bf16 MFMAs into one fp32 accumulator give the fp32 product to a relative 2^-26 per term - below the fp32 rounding of
+// the accumulation itself, which is all the exact-fp32 MFMA offers too (the same scheme k_sean_bwd_a_onehot<float> uses for
+// its G operand).  6/16 of the fp32 MFMA time, and with six MFMAs per operand byte the kernel is matrix-bound with slack on
+// LDS and DMA.
+//
+// Structure: the persistent LDS-DMA kernel of conv_bf16_v2.hip in its 8-wave form (16 x 32 output pixels x 32 NT channels per
+// item, one workgroup per CU, counted vmcnt, raw barriers, transposed accumulators).  Differences:
+//   * activations stay fp32 in HBM and in LDS: a halo chunk is 16 channels (64 bytes per pixel, the same LDS image and
+//     swizzle as a 32-channel bf16 chunk); a lane reads its 8 channels (2 x ds_read_b128) and splits them in registers
+//     (~44 VALU instructions per fragment triple, hidden under 48 MFMAs per wave and step);
+//   * the kernel is split ONCE per step by dasr_conv3x3_split_weights into a K-step-major image: for each (mode, slice,
+//     tap, 16-channel chunk) the three pieces of [32 NT rows][16 channels] lie contiguous and already swizzled, so a
+//     K-step's slice is one linear 12 KB (6 KB) LDS-DMA copy;
+//   * K-step = (tap, 16 channels): 2 rows x NT tiles x 6 products = 48 (24) MFMAs per wave, small pieces first;
+//   * fp32 output through the fp32 scratch path of the epilogue, 32 bytes per lane.
+#include "bf16.h"
+#include "conv_kernels.h"
+
+#define SP_HW 34
+#define SP_NWV 8
+#define SP_NTHR 512
+#define SP_TH 16
+#define SP_HPIX (18 * SP_HW)          // 612 halo pixels x 64 bytes (16 fp32 channels)
+#define SP_NHP 5                      // halo pieces per thread per chunk (2560 >= 2448)
+#define SP_HBYTES (SP_NHP * SP_NTHR * 16)
+#define SP_EPITCH 144
+
+DASR_DEVICE_CONST __attribute__((aligned(64))) unsigned sp_zero_page[64] = {0};
+
+struct ConvSplitArgs {
+    const float* x;          // [B,H,W,Cin] fp32 (dgrad: dconv, Cin = the layer's Cout)
+    const bf16_t* ws;        // this mode's split kernel image (dasr_conv3x3_split_weights)
+    const float* bias;       // [Cout] or null
+    float* y;                // [B,H,W,Cout]
+    int B, H, W, Cin, Cout, accumulate;
+    int tiles_x, tiles_y, nsl, nitems, Q, G8;
+};
+
+template <int N>
+__device__ __forceinline__ void sp_wait_vm() {
+#ifndef DASR_HIPEMU
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+// x = a0 + a1 + a2 exactly (each piece the bf16 rounding of what the previous ones left)
+__device__ __forceinline__ void sp_split3(const float (&x)[8], bf16x8& a0, bf16x8& a1, bf16x8& a2) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const bf16x2_t h0 = dasr_f2bf2(x[e], x[e + 1]);
+        const float r0 = x[e] - dasr_bf2f(h0[0]), r1 = x[e + 1] - dasr_bf2f(h0[1]);
+        const bf16x2_t h1 = dasr_f2bf2(r0, r1);
+        const float s0 = r0 - dasr_bf2f(h1[0]), s1 = r1 - dasr_bf2f(h1[1]);
+        const bf16x2_t h2 = dasr_f2bf2(s0, s1);
+        a0[e] = h0[0]; a0[e + 1] = h0[1];
+        a1[e] = h1[0]; a1[e + 1] = h1[1];
+        a2[e] = h2[0]; a2[e + 1] = h2[1];
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int NTILE = 32 * NT, PIECE = NTILE * 32, SLAB = 3 * PIECE;     // bytes: one bf16 piece [NTILE][16], a K-step's three
+    constexpr int WP = SLAB / 16;                                            // DMA pieces per slice: 768 / 384
+    constexpr int NFULL = WP / 64;                                           // waves 0 .. NFULL-1 carry the second / only piece
+    char* const sH = smem;                              // [2][SP_HBYTES]
+    char* const sW = smem + 2 * SP_HBYTES;              // [3][SLAB]
+    float* const sBias = (float*)(sW + 3 * SLAB);       // [Cout]
+    const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
+    const int li = lane & 31, lh = lane >> 5;
+    // DMA pieces of a kernel slice per thread: NT = 4: 768 = 512 + 256 (waves 0-3 two, waves 4-7 one);
+    // NT = 2: 384 (waves 0-5 one, waves 6-7 none).  A wave's count is static: cls picks its wait constants.
+    const int nwq = NT == 4 ? (wv < 4 ? 2 : 1) : (wv < 6 ? 1 : 0);
+    const dasr_lds_addr_t ldsH = DASR_LDS_ADDR(sH) + 1024 * wv, ldsW = DASR_LDS_ADDR(sW) + 1024 * wv;
+
+    const int xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3;
+    const int ibeg = xcd * a.Q;
+    const int iend = ibeg + a.Q < a.nitems ? ibeg + a.Q : a.nitems;
+    int item = ibeg + jwg;
+    if (item >= iend) return;
+    const int NC = a.Cin >> 4;
+    const int pixb = a.Cin * 4, rowb = a.W * pixb;
+    const size_t sampb = (size_t)a.H * rowb;
+    const char* const zp = (const char*)sp_zero_page;
+
+    for (int i = tid; i < a.Cout; i += SP_NTHR) sBias[i] = a.bias ? a.bias[i] : 0.f;
+    __syncthreads();
+
+    int x0, y0, n0, bb;
+    auto decode = [&](int it, int& ox0, int& oy0, int& on0, int& ob) {
+        const int ns = it % a.nsl, pt = it / a.nsl;
+        const int tile = pt % (a.tiles_x * a.tiles_y);
+        ob = pt / (a.tiles_x * a.tiles_y);
+        ox0 = (tile % a.tiles_x) * 32;
+        oy0 = (tile / a.tiles_x) * SP_TH;
+        on0 = ns * NTILE;
+    };
+    decode(item, x0, y0, n0, bb);
+    int hoff[SP_NHP];
+    unsigned hok = 0;
+    const char* hxb;
+    auto halo_setup = [&](int fx0, int fy0, int fb, bool real) {
+        hxb = (const char*)a.x + (size_t)fb * sampb;
+        const int org = (fy0 - 1) * rowb + (fx0 - 1) * pixb;
+        int t = tid;
+#ifndef DASR_HIPEMU
+        asm volatile("" : "+v"(t));
+#endif
+        hok = 0;
+#pragma unroll
+        for (int u = 0; u < SP_NHP; ++u) {
+            const int P = (t >> 2) + (SP_NTHR / 4) * u;
+            const int pr = P / SP_HW, pc = P - pr * SP_HW;
+            hoff[u] = org + pr * rowb + pc * pixb + 16 * ((t & 3) ^ ((P >> 2) & 3));
+            const bool ok = real && P < SP_HPIX && (unsigned)(fy0 - 1 + pr) < (unsigned)a.H && (unsigned)(fx0 - 1 + pc) < (unsigned)a.W;
+            hok |= ok ? (1u << u) : 0u;
+        }
+    };
+    auto halo_issue = [&](int u, int cc, int buf) {
+        const char* src = ((hok >> u) & 1u) ? hxb + hoff[u] + 64 * cc : zp;
+        DASR_GLDS16(src, ldsH + buf * SP_HBYTES + 1024 * SP_NWV * u);
+    };
+    // slice of K-step (slice index ns, tap, chunk cc): contiguous SLAB bytes at ((ns * 9 + tap) * NC + cc) * SLAB
+    auto w_issue = [&](int cc, int tap, int fn0) {
+        const char* src = (const char*)a.ws + (size_t)(((fn0 / NTILE) * 9 + tap) * NC + cc) * SLAB + 16 * tid;
+        const dasr_lds_addr_t dst = ldsW + (tap % 3) * SLAB;
+        if (NT == 4 || wv < NFULL) DASR_GLDS16(src, dst);                               // pieces 0 .. 511 (NT = 2: 0 .. 383)
+        if (NT == 4 && wv < 4) DASR_GLDS16(src + 16 * SP_NTHR, dst + 1024 * SP_NWV);    // pieces 512 .. 767
+    };
+
+    const int Pl = 2 * wv * SP_HW + li;
+    const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4);
+
+    int par = 0;
+    halo_setup(x0, y0, bb, true);
+#pragma unroll
+    for (int u = 0; u < SP_NHP; ++u) halo_issue(u, 0, 0);
+    w_issue(0, 0, n0);
+    w_issue(0, 1, n0);
+
+    for (;;) {
+        const int nitem = item + a.G8;
+        const bool has_next = nitem < iend;
+        int nx0 = x0, ny0 = y0, nn0 = n0, nb = bb;
+        if (has_next) decode(nitem, nx0, ny0, nn0, nb);
+
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(sBias + n0 + 32 * n + 8 * g + 4 * lh);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m][n][4 * g] = bv.x; acc[m][n][4 * g + 1] = bv.y;
+                    acc[m][n][4 * g + 2] = bv.z; acc[m][n][4 * g + 3] = bv.w;
+                }
+            }
+
+        for (int cc = 0; cc < NC; ++cc) {
+            const bool last = cc == NC - 1;
+            if (last) halo_setup(nx0, ny0, nb, has_next);
+            const int fcc = last ? 0 : cc + 1;
+            const char* const hb = sH + par * SP_HBYTES;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // all but the operations of the previous step (its halo piece, this wave's pieces of W(step + 1)) are done
+                {
+                    const int h = ((tap + 8) % 9) < SP_NHP ? 1 : 0;
+                    if (nwq == 2)      { if (h) sp_wait_vm<3>(); else sp_wait_vm<2>(); }
+                    else if (nwq == 1) { if (h) sp_wait_vm<2>(); else sp_wait_vm<1>(); }
+                    else               { if (h) sp_wait_vm<1>(); else sp_wait_vm<0>(); }
+                }
+                DASR_RAW_BARRIER();
+                if (tap < SP_NHP) halo_issue(tap, fcc, par ^ 1);
+                if (tap + 2 < 9) w_issue(cc, tap + 2, n0);
+                else             w_issue(fcc, tap + 2 - 9, last ? nn0 : n0);
+
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                const char* const wb = sW + (tap % 3) * SLAB + boff;
+                int Pq = Pl;
+#ifndef DASR_HIPEMU
+                asm volatile("" : "+v"(Pq));
+#endif
+                bf16x8 A[2][3];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int P = Pq + (m + dy) * SP_HW + dx;
+                    const int key = (P >> 2) & 3;
+                    const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
+                    const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
+                    const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    sp_split3(xv, A[m][0], A[m][1], A[m][2]);
+                }
+                DASR_SETPRIO(1);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const bf16x8 B0 = *(const bf16x8*)(wb + n * 1024);
+                    const bf16x8 B1 = *(const bf16x8*)(wb + PIECE + n * 1024);
+                    const bf16x8 B2 = *(const bf16x8*)(wb + 2 * PIECE + n * 1024);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        // smallest terms first: x0 w2 + x1 w1 + x2 w0, then x0 w1 + x1 w0, then x0 w0
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2, A[m][0], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A[m][1], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][2], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A[m][0], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][1], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][0], acc[m][n], 0, 0, 0);
+                    }
+                }
+                DASR_SETPRIO(0);
+            }
+            par ^= 1;
+        }
+
+        // ---- epilogue: 32 channels per pass through [pixel][32 + 4] fp32, 32 bytes per lane out
+        DASR_RAW_BARRIER();
+        char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
+        const int wvalid = a.W - x0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int gy = y0 + 2 * wv + m;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 pk = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+                    *(f32x4*)(scr + li * SP_EPITCH + (8 * g + 4 * lh) * 4) = pk;
+                }
+                DASR_WAVE_SYNC();
+                if (gy < a.H) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int v = lane + 64 * u, pix = v >> 2, cg = v & 3;
+                        if (pix >= wvalid) continue;
+                        float4 lo = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg);
+                        float4 hi = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg + 16);
+                        float* yp = a.y + (((size_t)bb * a.H + gy) * a.W + x0 + pix) * a.Cout + n0 + 32 * n + 8 * cg;
+                        if (a.accumulate) {
+                            const float4 o0 = *(const float4*)yp, o1 = *(const float4*)(yp + 4);
+                            lo = make_float4(lo.x + o0.x, lo.y + o0.y, lo.z + o0.z, lo.w + o0.w);
+                            hi = make_float4(hi.x + o1.x, hi.y + o1.y, hi.z + o1.z, hi.w + o1.w);
+                        }
+                        *(float4*)yp = lo;
+                        *(float4*)(yp + 4) = hi;
+                    }
+                }
+                DASR_WAVE_SYNC();
+            }
+        }
+        if (!has_next) break;
+        item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
+    }
+    sp_wait_vm<0>();
+}
+
+// ---- the kernel split: fp32 packed [2][9][Cin][Cout] (plane 0 = HWIO) -> bf16 image of both modes
+//   ws[mode][slice][tap][chunk][piece j][row r][16],  element kk of row r at half (kk >> 3) ^ ((r >> 3) & 1)
+//   mode 0 (forward): rows = output channels, K = input channels:  w[tap][16 chunk + kk][slice * NTILE + r]
+//   mode 1 (dgrad):   rows = input channels,  K = output channels: w[8 - tap][slice * NTILE + r][16 chunk + kk]
+__host__ __device__ static inline int sp_ntile(int N) { return (N % 128) == 0 ? 128 : 64; }
+__global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__ w, bf16_t* __restrict__ ws, int Cin, int Cout) {
+    const size_t per_mode = (size_t)27 * Cin * Cout;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < 2 * (size_t)9 * Cin * Cout; idx += (size_t)gridDim.x * 256) {
+        const int mode = idx >= (size_t)9 * Cin * Cout;
+        size_t e = idx - (size_t)mode * 9 * Cin * Cout;
+        const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+        const int NTILE = sp_ntile(N), NCk = K / 16;
+        // e enumerates (slice, tap, chunk, row, kk)
+        const int kk = (int)(e % 16); e /= 16;
+        const int r = (int)(e % NTILE); e /= NTILE;
+        const int cc = (int)(e % NCk); e /= NCk;
+        const int tap = (int)(e % 9);
+        const int ns = (int)(e / 9);
+        const int n = ns * NTILE + r, k = 16 * cc + kk;
+        const float v = mode == 0 ? w[((size_t)tap * Cin + k) * Cout + n] : w[((size_t)(8 - tap) * Cin + n) * Cout + k];
+        const bf16_t h0 = dasr_f2bf(v);
+        const float r1 = v - dasr_bf2f(h0);
+        const bf16_t h1 = dasr_f2bf(r1);
+        const bf16_t h2 = dasr_f2bf(r1 - dasr_bf2f(h1));
+        const size_t slab = (((size_t)ns * 9 + tap) * NCk + cc) * 3 * NTILE * 16;
+        const int pos = r * 16 + (((kk >> 3) ^ ((r >> 3) & 1)) << 3) + (kk & 7);
+        bf16_t* o = ws + (size_t)mode * per_mode + slab + pos;
+        o[0] = h0;
+        o[(size_t)NTILE * 16] = h1;
+        o[(size_t)2 * NTILE * 16] = h2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+static bool sp_ok(int H, int W, int K, int N) {
+    return H > 0 && W > 0 && (K % 16) == 0 && (N % 64) == 0 && N <= 1024 && (size_t)H * W * (K > N ? K : N) * 4 < ((size_t)1 << 31);
+}
+extern "C" int dasr_conv3x3_split_supported(int H, int W, int Cin, int Cout) {
+    return (sp_ok(H, W, Cin, Cout) && sp_ok(H, W, Cout, Cin)) ? 1 : 0;      // forward and dgrad
+}
+extern "C" size_t dasr_conv3x3_split_weights_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return sizeof(bf16_t) * (size_t)54 * Cin * Cout;
+}
+extern "C" int dasr_conv3x3_split_weights(const float* w_packed, unsigned short* w_split, int Cin, int Cout, void* stream) {
+    DASR_CHECK_PTR(w_packed); DASR_CHECK_PTR(w_split);
+    DASR_CHECK_SHAPE(Cin > 0 && Cout > 0 && (Cin % 64) == 0 && (Cout % 64) == 0);
+    DASR_LAUNCH(k_split_weights, dim3(dasr_ew_grid((size_t)18 * Cin * Cout)), dim3(256), 0, stream, w_packed, (bf16_t*)w_split, Cin, Cout);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+static int sp_launch(ConvSplitArgs& a, void* stream) {
+    const int NT = (a.Cout % 128) == 0 ? 4 : 2;
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + SP_TH - 1) / SP_TH;
+    a.nsl = a.Cout / (32 * NT);
+    a.nitems = a.tiles_x * a.tiles_y * a.B * a.nsl;
+    a.Q = (a.nitems + 7) / 8;
+    a.G8 = a.Q < 32 ? a.Q : 32;
+    if ((dasr_get_conv_bf16_impl() & 3) == 2) a.G8 = 1;        // tests: one workgroup per XCD walks every item of it
+    const size_t lds = 2 * (size_t)SP_HBYTES + 3 * (size_t)(3 * 32 * NT * 32) + sizeof(float) * (size_t)a.Cout;
+    const dim3 grid(8 * a.G8);
+    if (NT == 4) DASR_LAUNCH((k_conv3x3_split<4>), grid, dim3(SP_NTHR), lds, stream, a);
+    else         DASR_LAUNCH((k_conv3x3_split<2>), grid, dim3(SP_NTHR), lds, stream, a);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+extern "C" int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const float* bias, float* y, int B, int H,
+                                      int W, int Cin, int Cout, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(w_split); DASR_CHECK_PTR(y);
+    DASR_CHECK_SHAPE(B > 0);
+    if (!dasr_conv3x3_split_supported(H, W, Cin, Cout)) return DASR_E_UNSUPPORTED;
+    ConvSplitArgs a{x, (const bf16_t*)w_split, bias, y, B, H, W, Cin, Cout, 0, 0, 0, 0, 0, 0, 0};
+    return sp_launch(a, stream);
+}
+// dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * w[tap][ci][co]: mode 1 of the split image (taps already flipped)
+extern "C" int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short* w_split, float* dx, int accumulate, int B,
+                                        int H, int W, int Cin, int Cout, void* stream) {
+    DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(w_split); DASR_CHECK_PTR(dx);
+    DASR_CHECK_SHAPE(B > 0);
+    if (!dasr_conv3x3_split_supported(H, W, Cin, Cout)) return DASR_E_UNSUPPORTED;
+    ConvSplitArgs a{dconv, (const bf16_t*)w_split + (size_t)27 * Cin * Cout, nullptr, dx, B, H, W, Cout, Cin, accumulate,
+                    0, 0, 0, 0, 0, 0};
+    return sp_launch(a, stream);
+}

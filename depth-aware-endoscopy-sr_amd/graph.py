@@ -32,6 +32,11 @@ import threading as _threading
 TAIL_WGRAD_SIDE = False  # weight gradients of the HR tail on the (then idle) depth-branch stream; see conv(side_wgrad=)
 FUSE_INSTNORM_STATS = False  # measured: 115.5 -> 111.5 frames/s when on (two more barriers + reductions in the 64->64 conv epilogue cost more than the statistics pass they replace); the entry point stays, tested
 ENCODER_S2D = True     # bf16 path: encoder layers 2-5 on the bf16 stride-1 kernels (space-to-depth form); False: fp32 gather kernels
+# fp32 path: the plain (bias-only) 3x3 trunk convolutions - gamma_o|beta_o 128 -> 128 and the DGB 64 -> 64 ones, forward and
+# dgrad - at fp32 accuracy on the BF16 matrix cores (csrc/conv_split_bf16.hip: three bf16 pieces per operand, six products).
+# Weight gradients stay on the exact-fp32 MFMA kernels.
+SPLIT_BF16 = True
+SPLIT_MIN_PIXELS = 1 << 14      # below this the launch is latency-bound either way
 WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
 _SIDE_LOCK = _threading.Lock()
@@ -156,6 +161,13 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
         # the InstanceNorm statistics of the output come out of the convolution's epilogue (no second pass over y)
         y, mean, var = ops.conv2d_fwd_stats(x.data, w.data, bias.data if bias is not None else None)
         stats = (mean, var)
+    elif (SPLIT_BF16 and f32 and w.data.dtype == torch.float32 and act == ops.ACT_NONE and ps_r == 1 and residual is None
+          and stride == 1 and pad == 1 and not transposed and tuple(w.data.shape[1:3]) == (3, 3)
+          and x.data.shape[0] * x.data.shape[1] * x.data.shape[2] >= SPLIT_MIN_PIXELS
+          and ops.conv3x3_split_supported(x.data.shape[1], x.data.shape[2], w.data.shape[3], w.data.shape[4])):
+        if w.split is None:
+            w.split = ops.conv3x3_split_weights(w.data)
+        y = ops.conv3x3_fwd_split(x.data, w.split, bias.data if bias is not None else None, w.data.shape[4])
     else:
         y = ops.conv2d_fwd(x.data, w.data, bias.data if bias is not None else None,
                            residual.data if residual is not None else None, stride, pad, transposed, act, ps_r, out_dtype)
@@ -226,6 +238,11 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
                 x.grad = ops.conv2d_dgrad_act(dconv, w.data, x.data, x.epilogue[0], x.epilogue[1], stride, pad,
                                               transposed)
                 x.grad_is_preact = True
+            elif w.split is not None:
+                if x.grad is None:
+                    x.grad = ops.conv3x3_dgrad_split(dconv, w.split, x.data.shape)
+                else:
+                    ops.conv3x3_dgrad_split(dconv, w.split, x.data.shape, out=x.grad)
             elif x.grad is None:
                 x.grad = ops.conv2d_dgrad(dconv, w.data, x.data.shape, stride, pad, transposed, out_dtype=x.data.dtype)
             else:

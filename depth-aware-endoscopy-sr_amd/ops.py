@@ -384,6 +384,38 @@ def conv2d_wgrad_act(x, dy, y, w_shape, act, stride=1, pad=1, transposed=False, 
     return dw, db
 
 
+# ---- fp32 convolutions on the bf16 matrix cores (split bf16) --------------------------------
+def conv3x3_split_supported(H, W, Cin, Cout):
+    return bool(_lib.get().dasr_conv3x3_split_supported(H, W, Cin, Cout))
+
+
+def conv3x3_split_weights(w):
+    """fp32 packed kernel (2,3,3,Cin,Cout) -> the bf16 three-piece image both split kernels read."""
+    KH, KW, Cin, Cout = _wdims(w)
+    assert (KH, KW) == (3, 3) and w.dtype == torch.float32
+    n = int(_lib.get().dasr_conv3x3_split_weights_bytes(Cin, Cout)) // 2
+    ws = torch.empty((n,), dtype=BF16, device=w.device)
+    _call("dasr_conv3x3_split_weights", _p(w), _pa(ws), Cin, Cout)
+    return ws
+
+
+def conv3x3_fwd_split(x, ws, bias, Cout):
+    B, H, W, Cin = x.shape
+    y = empty((B, H, W, Cout), x)
+    _call("dasr_conv3x3_fwd_split", _p(x), _pa(ws), _p(bias, True), _p(y), B, H, W, Cin, Cout)
+    return y
+
+
+def conv3x3_dgrad_split(dconv, ws, x_shape, out=None):
+    B, H, W, Cin = x_shape
+    Cout = dconv.shape[3]
+    acc = out is not None
+    if out is None:
+        out = empty(tuple(x_shape), dconv)
+    _call("dasr_conv3x3_dgrad_split", _p(dconv), _pa(ws), _p(out), 1 if acc else 0, B, H, W, Cin, Cout)
+    return out
+
+
 def conv2d_fwd_stats(x, w, bias):
     """3x3 / stride 1 / pad 1 conv (+bias) and the InstanceNorm statistics of its output: (y, mean[B,C], var[B,C])."""
     B, H, W, Cin = x.shape

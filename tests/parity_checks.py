@@ -1076,6 +1076,56 @@ def check_region_shortcut_invalidation(device):
     return dict(ok=True)
 
 
+def check_split_conv(device, seed=5):
+    """dasr_conv3x3_{fwd,dgrad}_split - fp32 convolutions as six bf16 MFMA products of three-piece operands - against
+    torch's FLOAT64 convolution of the same fp32 operands, next to the exact-fp32 MFMA kernels they replace
+    (dasr_conv2d_fwd / dasr_conv2d_dgrad): the split kernels must be as close to the float64 result as the fp32 kernels are
+    (gate: error <= 2x the fp32 kernel's + 2e-7 of the largest value; measured: equal or smaller).  Ragged tiles, one to
+    four channel slices' worth of rows, 64 / 128 / 256 channels, accumulating dgrad, and - second pass - one workgroup per
+    XCD walking a list of items."""
+    gen = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    out = {}
+    for one_wg in (False, True):
+        ops.set_conv_bf16_impl(2 if one_wg else 0)
+        try:
+            for (cin, cout, B, H, W) in [(64, 64, 1, 17, 35), (128, 128, 1, 16, 32), (128, 64, 2, 33, 40), (64, 256, 1, 9, 70)]:
+                x = rn(B, cin, H, W) * (1.0 + rn(B, cin, 1, 1).abs())
+                w = rn(cout, cin, 3, 3) * (1.0 / math.sqrt(9 * cin))
+                bias = rn(cout) * 0.3
+                x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double()
+                ref = F.conv2d(x64, w64, b64, padding=1)
+                dy = rn(B, cout, H, W)
+                gx64, = torch.autograd.grad(ref, x64, dy.double())
+                assert ops.conv3x3_split_supported(H, W, cin, cout)
+                xd = nhwc(x).to(device)
+                wp = ops.pack_hwio(w.permute(2, 3, 1, 0).contiguous().to(device))
+                ws = ops.conv3x3_split_weights(wp)
+                bd = bias.to(device)
+                y_sp = ops.conv3x3_fwd_split(xd, ws, bd, cout)
+                y_32 = ops.conv2d_fwd(xd, wp, bd)
+                e_sp = (nchw(y_sp.cpu()).double() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
+                e_32 = (nchw(y_32.cpu()).double() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
+                assert e_sp <= 2 * e_32 + 2e-7, ("fwd", cin, cout, H, W, e_sp, e_32)
+                dyd = nhwc(dy).to(device)
+                dx_sp = ops.conv3x3_dgrad_split(dyd, ws, xd.shape)
+                dx_32 = ops.conv2d_dgrad(dyd, wp, xd.shape)
+                g_sp = (nchw(dx_sp.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
+                g_32 = (nchw(dx_32.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
+                assert g_sp <= 2 * g_32 + 2e-7, ("dgrad", cin, cout, H, W, g_sp, g_32)
+                base = rn(B, H, W, cin)
+                accd = base.to(device).clone()
+                ops.conv3x3_dgrad_split(dyd, ws, xd.shape, out=accd)
+                want = nhwc(gx64) + base.double()
+                g_acc = (accd.cpu().double() - want).abs().max().item() / want.abs().max().item()
+                assert g_acc <= 2 * g_32 + 4e-7, ("dgrad accumulate", cin, cout, g_acc)
+                out["%d->%d %dx%d%s" % (cin, cout, H, W, " 1wg" if one_wg else "")] = tuple(
+                    float("%.3g" % v) for v in (e_sp, e_32, g_sp, g_32, g_acc))
+        finally:
+            ops.set_conv_bf16_impl(0)
+    return out
+
+
 # =====================================================================================================================
 # Mixed precision (bf16 activations; BASELINE.json configs[2..3])
 # =====================================================================================================================

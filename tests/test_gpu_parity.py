@@ -28,6 +28,23 @@ def test_pixel_shuffle_bit_exact():
     pc.check_pixel_shuffle_bit_exact("cuda")
 
 
+def test_split_conv():
+    print(pc.check_split_conv("cuda"))
+
+
+@pytest.mark.parametrize("case", DEPTHNET_CASES, ids=[c["name"] for c in DEPTHNET_CASES])
+def test_depthnet_split_bf16(case):
+    """The whole-net golden cases with the split-bf16 convolutions FORCED on (by default they take over above
+    graph.SPLIT_MIN_PIXELS pixels only, i.e. never at these tiny frames): the fp32 gates, unchanged."""
+    from dasr_amd import graph
+    old = graph.SPLIT_MIN_PIXELS
+    graph.SPLIT_MIN_PIXELS = 0
+    try:
+        print(case["name"], "split", pc.check_depthnet_case(case, "cuda"))
+    finally:
+        graph.SPLIT_MIN_PIXELS = old
+
+
 def test_sean():
     pc.check_sean_golden("cuda")
 

@@ -13,6 +13,10 @@ def test_conv_variants(emu):
     pc.check_conv_variants("cpu")
 
 
+def test_split_conv(emu):
+    print(pc.check_split_conv("cpu"))
+
+
 def test_pixel_shuffle_bit_exact(emu):
     pc.check_pixel_shuffle_bit_exact("cpu")
 
