@@ -32,6 +32,44 @@ def test_split_conv():
     print(pc.check_split_conv("cuda"))
 
 
+def test_graphed_trainer_matches_eager():
+    """harness.Trainer(use_graph=True): three eager steps, one captured, then replays - against the eager trainer on the same
+    batches (which change every step: the loader's tensors are copied into the captured ones, region bytes included).
+    Training is chaotic at this scale (Adam turns the rounding noise of mathematically-zero gradients into +-lr steps, and
+    the weight-gradient slabs are summed with atomics), so the two runs may drift: the loss of every step agrees to 3e-3
+    (consecutive steps see different batches and differ by 10-30 %: stale captured inputs would show), and the accumulated
+    parameter updates point the same way (cosine >= 0.98 over all parameters with a defined gradient)."""
+    from dasr_amd import harness, prep
+    case = dict(name="graph", scale=8, which=[0, 1, 2], L=32, nb=5, B=2, H=16, W=20)
+    runs = {}
+    net0, _ = pc.build_net(case, "cuda")
+    init = {k: v.detach().clone() for k, v in net0.state_dict().items()}
+    for use_graph in (False, True):
+        net, cfg = pc.build_net(case, "cuda")
+        tr = harness.Trainer(net, use_graph=use_graph)
+        losses = []
+        for step in range(7):
+            lq, gt, dm, _ = pc.synth.seeded_batch(10 * step, 2, 16, 20, 8)
+            lq, gt, dm = lq.cuda(), gt.cuda(), dm.cuda()
+            mk = prep.depth_to_masks(dm, 10)
+            log = tr.optimize_parameters(lq, gt, dm, mk)
+            losses.append(float(log["l_all"]))
+        assert (tr._graph is not None) == use_graph
+        runs[use_graph] = (losses, {k: v.detach().clone() for k, v in net.state_dict().items()})
+    le, lg = runs[False][0], runs[True][0]
+    assert all(abs(a - b) <= 3e-3 * max(1.0, abs(a)) for a, b in zip(le, lg)), (le, lg)
+    assert max(le) - min(le) > 0.2, le                        # the batches do differ
+    dot = na = nb = 0.0
+    for k, v0 in init.items():
+        if any(z in k for z in pc.ZERO_GRAD_KEYS):
+            continue
+        ua, ub = (runs[False][1][k] - v0).double().flatten(), (runs[True][1][k] - v0).double().flatten()
+        dot += float(ua @ ub); na += float(ua @ ua); nb += float(ub @ ub)
+    worst = dot / (na * nb) ** 0.5
+    assert worst >= 0.98, worst
+    print("graphed vs eager: losses", le, lg, "update cosine", worst)
+
+
 @pytest.mark.parametrize("case", DEPTHNET_CASES, ids=[c["name"] for c in DEPTHNET_CASES])
 def test_depthnet_split_bf16(case):
     """The whole-net golden cases with the split-bf16 convolutions FORCED on (by default they take over above
