@@ -348,3 +348,202 @@ extern "C" int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short
                     0, 0, 0, 0, 0, 0};
     return sp_launch(a, stream);
 }
+
+// ------------------------------------------------------------------------------------------ weight gradient
+// dW[tap][ci][co] = sum_p x[p + off(tap), ci] * dconv[p, co] with the same three-piece operands: M = ci, N = co, K = pixels,
+// 16 per MFMA.  Structure of k_conv3x3_wgrad_mfma<2, 2> (conv_mfma.hip): a workgroup of four waves owns a 64 x 64 block of
+// (ci, co) for all nine taps (nine resident 32 x 32 accumulators per wave), walks a strip of 2 x 32 pixel tiles staged in
+// LDS as fp32 ([pixel][channel], 51 KB, two workgroups per CU), writes its partial dW as a slab; k_wgrad_reduce sums the slabs.
+// What changes is the K loop: a K-step is 16 consecutive pixels of a tile row; a lane reads ITS channel of 8 of them for the
+// dconv operand and of 10 of them per kernel row for the three taps of that row (their 8-pixel windows start one pixel
+// apart), 38 conflict-free ds_read_b32, splits them in registers and issues 9 taps x 6 products = 54 bf16 MFMAs - against
+// 8 x 9 = 72 exact-fp32 MFMAs of twice the duration each for the same 16 pixels.
+#define SW_TW 32
+#define SW_TH 2
+
+struct SplitWgradArgs {
+    const float* x;      // [B,H,W,Cin]
+    const float* dy;     // [B,H,W,Cout]
+    float* slabs;        // [P][9][Cin][Cout]
+    float* bslabs;       // [P][Cout] or null
+    float* zero;         // dw when the reduction adds into it with atomics, else null: zeroed here
+    size_t nzero;
+    int B, H, W, Cin, Cout;
+    int P, ntiles;
+};
+
+// one value -> its three bf16 pieces, two values at a time (one v_cvt_pk_bf16_f32 per piece and pair)
+__device__ __forceinline__ void sp_split_pair(float v0, float v1, bf16x2_t& h0, bf16x2_t& h1, bf16x2_t& h2) {
+    h0 = dasr_f2bf2(v0, v1);
+    const float r0 = v0 - dasr_bf2f(h0[0]), r1 = v1 - dasr_bf2f(h0[1]);
+    h1 = dasr_f2bf2(r0, r1);
+    h2 = dasr_f2bf2(r0 - dasr_bf2f(h1[0]), r1 - dasr_bf2f(h1[1]));
+}
+
+__global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int CIG = 64, COG = 64, TH = SW_TH, HW = SW_TW + 2;
+    float* sX = (float*)smem;                                   // [(TH+2)*HW][CIG]
+    float* sD = sX + (TH + 2) * HW * CIG;                       // [TH*TW][COG]
+    const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
+    const int li = lane & 31, lh = lane >> 5;
+    const int mt = wv >> 1, nt = wv & 1;
+    const int cgroups = a.Cout / COG;
+    const int ci0 = (blockIdx.x / cgroups) * CIG, co0 = (blockIdx.x % cgroups) * COG;
+    const int tiles_x = (a.W + SW_TW - 1) / SW_TW, tiles_y = (a.H + TH - 1) / TH;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool do_bias = a.bslabs != nullptr && ci0 == 0 && tid < COG;
+    float bsum = 0.f;
+    if (a.zero) {
+        const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
+        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
+    }
+
+    for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx * SW_TW, y0 = ty * TH;
+        // stage the tile: every global load of a thread before the first LDS write (see k_conv3x3_wgrad_mfma)
+        constexpr int NX = (TH + 2) * HW * (CIG / 4), NXI = (NX + 255) / 256;        // 2176 float4 pieces: 9 per thread
+        constexpr int ND = TH * SW_TW * (COG / 4), NDI = (ND + 255) / 256;           // 1024: 4 per thread
+        // (144 accumulator registers are resident: the x pieces go in two batches, the second one after the barrier)
+        constexpr int XA = 4;
+        float4 vx[NXI - XA > XA ? NXI - XA : XA], vd[NDI];
+        auto ldx = [&](int u) {
+            const int idx = tid + 256 * u;
+            const int c4 = idx % (CIG / 4), pix = idx / (CIG / 4);
+            const int gy = y0 + pix / HW - 1, gx = x0 + pix % HW - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
+            return v;
+        };
+        auto stx = [&](int u, float4 v) {
+            const int idx = tid + 256 * u;
+            if (idx < NX) *(float4*)(sX + (idx / (CIG / 4)) * CIG + 4 * (idx % (CIG / 4))) = v;
+        };
+#pragma unroll
+        for (int u = 0; u < XA; ++u) vx[u] = ldx(u);
+#pragma unroll
+        for (int u = 0; u < NDI; ++u) {
+            const int idx = tid + 256 * u;
+            const int c4 = idx % (COG / 4), pix = idx / (COG / 4);
+            const int gy = y0 + pix / SW_TW, gx = x0 + pix % SW_TW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < a.H && gx < a.W)
+                v = *(const float4*)(a.dy + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * c4);
+            vd[u] = v;
+        }
+        __syncthreads();                        // every wave is done with the previous tile
+#pragma unroll
+        for (int u = 0; u < XA; ++u) stx(u, vx[u]);
+#pragma unroll
+        for (int u = 0; u < NDI; ++u) {
+            const int idx = tid + 256 * u;
+            *(float4*)(sD + (idx / (COG / 4)) * COG + 4 * (idx % (COG / 4))) = vd[u];
+        }
+#pragma unroll
+        for (int u = XA; u < NXI; ++u) vx[u - XA] = ldx(u);
+#pragma unroll
+        for (int u = XA; u < NXI; ++u) stx(u, vx[u - XA]);
+        __syncthreads();
+        if (do_bias) {
+#pragma unroll 8
+            for (int px = 0; px < TH * SW_TW; ++px) bsum += sD[px * COG + tid];
+        }
+#pragma unroll 1
+        for (int s = 0; s < TH * 2; ++s) {
+            const int py = s >> 1, pc = 16 * (s & 1) + 8 * lh;       // this lane's first pixel column of the K-step
+            // dconv operand: 8 pixels of channel co0 + 32 nt + li
+            bf16x8 B0, B1, B2;
+            {
+                const float* dp = sD + (py * SW_TW + pc) * COG + 32 * nt + li;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    bf16x2_t h0, h1, h2;
+                    sp_split_pair(dp[e * COG], dp[(e + 1) * COG], h0, h1, h2);
+                    B0[e] = h0[0]; B0[e + 1] = h0[1];
+                    B1[e] = h1[0]; B1[e + 1] = h1[1];
+                    B2[e] = h2[0]; B2[e + 1] = h2[1];
+                }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                // x operand: halo columns pc .. pc + 9 of halo row py + dy, channel ci0 + 32 mt + li: the three taps of this
+                // kernel row use columns dx .. dx + 7
+                const float* xp = sX + ((py + dy) * HW + pc) * CIG + 32 * mt + li;
+                bf16_t p0[10], p1[10], p2[10];
+#pragma unroll
+                for (int e = 0; e < 10; e += 2) {
+                    bf16x2_t h0, h1, h2;
+                    sp_split_pair(xp[e * CIG], xp[(e + 1) * CIG], h0, h1, h2);
+                    p0[e] = h0[0]; p0[e + 1] = h0[1];
+                    p1[e] = h1[0]; p1[e + 1] = h1[1];
+                    p2[e] = h2[0]; p2[e + 1] = h2[1];
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    bf16x8 A0, A1, A2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { A0[e] = p0[e + dx]; A1[e] = p1[e + dx]; A2[e] = p2[e + dx]; }
+                    f32x16 c = acc[3 * dy + dx];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, c, 0, 0, 0);
+                    acc[3 * dy + dx] = c;
+                }
+            }
+        }
+    }
+    if (do_bias) a.bslabs[(size_t)blockIdx.y * a.Cout + co0 + tid] = bsum;
+    float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = acc[tap][r];
+        }
+    }
+}
+
+static void sw_plan(int B, int H, int W, int Cin, int Cout, int& groups, int& ntiles, int& P) {
+    groups = (Cin / 64) * (Cout / 64);
+    ntiles = B * ((H + SW_TH - 1) / SW_TH) * ((W + SW_TW - 1) / SW_TW);
+    P = 512 / groups;
+    if (P < 1) P = 1;
+    if (P > ntiles) P = ntiles;
+}
+extern "C" size_t dasr_conv3x3_wgrad_split_workspace(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 64)) return 0;
+    int groups, ntiles, P;
+    sw_plan(B, H, W, Cin, Cout, groups, ntiles, P);
+    return sizeof(float) * ((size_t)P * 9 * Cin * Cout + (size_t)P * Cout);
+}
+extern "C" int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
+                                        size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(dw); DASR_CHECK_PTR(workspace);
+    DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0);
+    if ((Cin % 64) != 0 || (Cout % 64) != 0) return DASR_E_UNSUPPORTED;
+    if (workspace_bytes < dasr_conv3x3_wgrad_split_workspace(B, H, W, Cin, Cout)) return DASR_E_WORKSPACE;
+    int groups, ntiles, P;
+    sw_plan(B, H, W, Cin, Cout, groups, ntiles, P);
+    const size_t nW = (size_t)9 * Cin * Cout;
+    float* slabs = (float*)workspace;
+    float* bslabs = dbias ? slabs + (size_t)P * nW : nullptr;
+    // the slab sum meets in dw through atomics when it is split over blockIdx.y (the rule of wgrad_reduce_launch)
+    unsigned gx = dasr_cdiv(nW / 4, 256);
+    int ysplit = 1;
+    while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
+    SplitWgradArgs a{x, dconv, slabs, bslabs, ysplit > 1 ? dw : nullptr, ysplit > 1 ? nW : 0, B, H, W, Cin, Cout, P, ntiles};
+    const size_t lds = sizeof(float) * (size_t)((SW_TH + 2) * (SW_TW + 2) * 64 + SW_TH * SW_TW * 64);
+    DASR_LAUNCH(k_conv3x3_wgrad_split, dim3(groups, P), dim3(256), lds, stream, a);
+    return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit > 1, bslabs, dbias, Cout);
+}

@@ -36,6 +36,7 @@ ENCODER_S2D = True     # bf16 path: encoder layers 2-5 on the bf16 stride-1 kern
 # dgrad - at fp32 accuracy on the BF16 matrix cores (csrc/conv_split_bf16.hip: three bf16 pieces per operand, six products).
 # Weight gradients stay on the exact-fp32 MFMA kernels.
 SPLIT_BF16 = True
+SPLIT_WGRAD = True              # ... and their weight gradients (K = pixels: operands split at read time)
 SPLIT_MIN_PIXELS = 1 << 14      # below this the launch is latency-bound either way
 WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
@@ -211,7 +212,9 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             ws = _side_stream(dconv.device, "wgrad") if (WGRAD_STREAM and dconv.is_cuda) else None
             if ws is None and side_wgrad and TAIL_WGRAD_SIDE and SIDE_STREAM and dconv.is_cuda:
                 ws = _side_stream(dconv.device)       # the depth-branch stream: idle while the HR tail runs backward
-            if ws is None:
+            if ws is None and w.split is not None and SPLIT_WGRAD:
+                dw, db = ops.conv3x3_wgrad_split(x.data, dconv, want_bias=bias is not None)
+            elif ws is None:
                 dw, db = ops.conv2d_wgrad(x.data, dconv, wshape, stride, pad, transposed, want_bias=bias is not None)
             else:
                 cur = torch.cuda.current_stream()

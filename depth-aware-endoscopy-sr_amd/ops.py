@@ -406,6 +406,18 @@ def conv3x3_fwd_split(x, ws, bias, Cout):
     return y
 
 
+def conv3x3_wgrad_split(x, dconv, want_bias=True):
+    """(dw [3,3,Cin,Cout], dbias | None) of a plain 3x3 convolution, fp32, on the split-bf16 kernel."""
+    B, H, W, Cin = x.shape
+    Cout = dconv.shape[3]
+    nbytes = int(_lib.get().dasr_conv3x3_wgrad_split_workspace(B, H, W, Cin, Cout))
+    ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
+    dw = empty((3, 3, Cin, Cout), x)
+    db = empty((Cout,), x) if want_bias else None
+    _call("dasr_conv3x3_wgrad_split", _p(x), _p(dconv), _p(dw), _p(db, True), _p(ws), nbytes, B, H, W, Cin, Cout)
+    return dw, db
+
+
 def conv3x3_dgrad_split(dconv, ws, x_shape, out=None):
     B, H, W, Cin = x_shape
     Cout = dconv.shape[3]

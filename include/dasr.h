@@ -150,7 +150,9 @@ int dasr_conv2d_wgrad_act(const float* x, const float* dy, const float* y, float
  *   split_weights: the fp32 packed kernel [2][3][3][Cin][Cout] -> a bf16 image (split_weights_bytes) holding, for the
  *                  forward and the dgrad, the three pieces of every K-step's slice contiguously (once per step)
  *   fwd_split:     y = conv(x, w) + bias            x [B,H,W,Cin], y [B,H,W,Cout] fp32
- *   dgrad_split:   dx (+)= conv^T(dconv, w)         dconv [B,H,W,Cout], dx [B,H,W,Cin] fp32 */
+ *   dgrad_split:   dx (+)= conv^T(dconv, w)         dconv [B,H,W,Cout], dx [B,H,W,Cin] fp32
+ *   wgrad_split:   dw_hwio [3][3][Cin][Cout] = sum_pixels x (x) dconv, dbias (may be NULL) = sum dconv; workspace:
+ *                  dasr_conv3x3_wgrad_split_workspace() bytes (replaces dasr_conv2d_wgrad for these layers) */
 int dasr_conv3x3_split_supported(int H, int W, int Cin, int Cout);
 size_t dasr_conv3x3_split_weights_bytes(int Cin, int Cout);
 int dasr_conv3x3_split_weights(const float* w_packed, unsigned short* w_split, int Cin, int Cout, void* stream);
@@ -158,6 +160,9 @@ int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const 
                            int Cin, int Cout, void* stream);
 int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short* w_split, float* dx, int accumulate, int B, int H,
                              int W, int Cin, int Cout, void* stream);
+size_t dasr_conv3x3_wgrad_split_workspace(int B, int H, int W, int Cin, int Cout);
+int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, float* dw_hwio, float* dbias, void* workspace,
+                             size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
 
 /* ---- instance-norm statistics ---------------------------------------------------------------
  * nn.InstanceNorm2d(affine=False) appears twice in a row on every DGB conv output

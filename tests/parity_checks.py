@@ -1121,6 +1121,14 @@ def check_split_conv(device, seed=5):
                 g_sp = (nchw(dx_sp.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
                 g_32 = (nchw(dx_32.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
                 assert g_sp <= fac * g_32 + slack, ("dgrad", cin, cout, H, W, g_sp, g_32)
+                # weight / bias gradient
+                gw64, = torch.autograd.grad(F.conv2d(x64, w64, b64, padding=1), w64, dy.double())
+                gb64 = dy.double().sum((0, 2, 3))
+                dw_sp, db_sp = ops.conv3x3_wgrad_split(xd, dyd)
+                dw_32, db_32 = ops.conv2d_wgrad(xd, dyd, (3, 3, cin, cout))
+                w_sp, w_32 = rel_max(dw_sp.permute(3, 2, 0, 1), gw64), rel_max(dw_32.permute(3, 2, 0, 1), gw64)
+                assert w_sp <= fac * w_32 + slack, ("wgrad", cin, cout, H, W, w_sp, w_32)
+                assert rel_max(db_sp, gb64) <= 2 * rel_max(db_32, gb64) + 1e-6, ("dbias", cin, cout)
                 base = rn(B, H, W, cin)
                 accd = base.to(device).clone()
                 ops.conv3x3_dgrad_split(dyd, ws, xd.shape, out=accd)
@@ -1128,7 +1136,7 @@ def check_split_conv(device, seed=5):
                 g_acc = (accd.cpu().double() - want).abs().max().item() / want.abs().max().item()
                 assert g_acc <= fac * g_32 + 2 * slack, ("dgrad accumulate", cin, cout, g_acc)
                 out["%d->%d %dx%d%s" % (cin, cout, H, W, {0: "", 2: " 1wg"}[mode])] = tuple(
-                    float("%.3g" % v) for v in (e_sp, e_32, g_sp, g_32, g_acc))
+                    float("%.3g" % v) for v in (e_sp, e_32, g_sp, g_32, g_acc, w_sp, w_32))
         finally:
             ops.set_conv_bf16_impl(0)
     return out

@@ -34,12 +34,14 @@ def main():
         ws = ops.conv3x3_split_weights(wp)
         y = ops.conv2d_fwd(x, wp, bias)
         fl = 2.0 * 9 * ci * co * B * H * W
-        r = {k: [] for k in ("f32 fwd", "split fwd", "f32 dgrad", "split dgrad", "split weights")}
+        r = {k: [] for k in ("f32 fwd", "split fwd", "f32 dgrad", "split dgrad", "f32 wgrad", "split wgrad", "split weights")}
         for _ in range(3):
             r["f32 fwd"].append(timeit(lambda: ops.conv2d_fwd(x, wp, bias)))
             r["split fwd"].append(timeit(lambda: ops.conv3x3_fwd_split(x, ws, bias, co)))
             r["f32 dgrad"].append(timeit(lambda: ops.conv2d_dgrad(y, wp, x.shape)))
             r["split dgrad"].append(timeit(lambda: ops.conv3x3_dgrad_split(y, ws, x.shape)))
+            r["f32 wgrad"].append(timeit(lambda: ops.conv2d_wgrad(x, y, (3, 3, ci, co))))
+            r["split wgrad"].append(timeit(lambda: ops.conv3x3_wgrad_split(x, y)))
             r["split weights"].append(timeit(lambda: ops.conv3x3_split_weights(wp)))
         for k, v in r.items():
             us = sorted(v)[1]
