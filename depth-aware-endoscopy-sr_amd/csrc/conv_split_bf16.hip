@@ -40,8 +40,9 @@ struct ConvSplitArgs {
     const float* x;          // [B,H,W,Cin] fp32 (dgrad: dconv, Cin = the layer's Cout)
     const bf16_t* ws;        // this mode's split kernel image (dasr_conv3x3_split_weights)
     const float* bias;       // [Cout] or null
-    float* y;                // [B,H,W,Cout]
-    int B, H, W, Cin, Cout, accumulate;
+    const float* residual;   // [B,H,W,Cout] or null (added before the activation)
+    float* y;                // [B,H,W,Cout], or [B,2H,2W,Cout/4] with the PixelShuffle(2) store
+    int B, H, W, Cin, Cout, accumulate, act, ps_r;
     int tiles_x, tiles_y, nsl, nitems, Q, G8;
 };
 
@@ -79,8 +80,8 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
     const int li = lane & 31, lh = lane >> 5;
     // DMA pieces of a kernel slice per thread: NT = 4: 768 = 512 + 256 (waves 0-3 two, waves 4-7 one);
-    // NT = 2: 384 (waves 0-5 one, waves 6-7 none).  A wave's count is static: cls picks its wait constants.
-    const int nwq = NT == 4 ? (wv < 4 ? 2 : 1) : (wv < 6 ? 1 : 0);
+    // NT = 2: 384 (waves 0-5 one, waves 6-7 none); NT = 1: 192 (waves 0-2).  A wave's count is static.
+    const int nwq = NT == 4 ? (wv < 4 ? 2 : 1) : (wv < NFULL ? 1 : 0);      // NT = 2: waves 0-5, NT = 1: waves 0-2
     const dasr_lds_addr_t ldsH = DASR_LDS_ADDR(sH) + 1024 * wv, ldsW = DASR_LDS_ADDR(sW) + 1024 * wv;
 
     const int xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3;
@@ -224,10 +225,14 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
             par ^= 1;
         }
 
-        // ---- epilogue: 32 channels per pass through [pixel][32 + 4] fp32, 32 bytes per lane out
+        // ---- epilogue: 32 channels per pass through [pixel][32 + 4] fp32, 32 bytes per lane out; residual, activation,
+        // accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue
         DASR_RAW_BARRIER();
         char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
         const int wvalid = a.W - x0;
+        const bool is_relu = a.act == DASR_ACT_RELU;
+        const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
+        const bool has_act = a.act != DASR_ACT_NONE;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int gy = y0 + 2 * wv + m;
@@ -240,20 +245,52 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
                 }
                 DASR_WAVE_SYNC();
                 if (gy < a.H) {
+                    if (a.ps_r == 1) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int v = lane + 64 * u, pix = v >> 2, cg = v & 3;
-                        if (pix >= wvalid) continue;
-                        float4 lo = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg);
-                        float4 hi = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg + 16);
-                        float* yp = a.y + (((size_t)bb * a.H + gy) * a.W + x0 + pix) * a.Cout + n0 + 32 * n + 8 * cg;
-                        if (a.accumulate) {
-                            const float4 o0 = *(const float4*)yp, o1 = *(const float4*)(yp + 4);
-                            lo = make_float4(lo.x + o0.x, lo.y + o0.y, lo.z + o0.z, lo.w + o0.w);
-                            hi = make_float4(hi.x + o1.x, hi.y + o1.y, hi.z + o1.z, hi.w + o1.w);
+                        for (int u = 0; u < 2; ++u) {
+                            const int v = lane + 64 * u, pix = v >> 2, cg = v & 3;
+                            if (pix >= wvalid) continue;
+                            const float4 lo = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg);
+                            const float4 hi = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg + 16);
+                            float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                            const size_t idx = (((size_t)bb * a.H + gy) * a.W + x0 + pix) * a.Cout + n0 + 32 * n + 8 * cg;
+                            if (a.residual) {
+                                const float4 r0 = *(const float4*)(a.residual + idx), r1 = *(const float4*)(a.residual + idx + 4);
+                                o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w;
+                                o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
+                            }
+                            if (has_act) {
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) o[t] = is_relu ? fmaxf(o[t], 0.f) : fmaxf(o[t], o[t] * slope);
+                            }
+                            float* yp = a.y + idx;
+                            if (a.accumulate) {
+                                const float4 o0 = *(const float4*)yp, o1 = *(const float4*)(yp + 4);
+                                o[0] += o0.x; o[1] += o0.y; o[2] += o0.z; o[3] += o0.w;
+                                o[4] += o1.x; o[5] += o1.y; o[6] += o1.z; o[7] += o1.w;
+                            }
+                            *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
+                            *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
                         }
-                        *(float4*)yp = lo;
-                        *(float4*)(yp + 4) = hi;
+                    } else {
+                        // PixelShuffle(2): out[b, 2gy+i, 2gx+j, c] = conv[b, gy, gx, 4c + 2i + j]: 8 values of c per (pixel, sub-pixel)
+                        const int Cq = a.Cout / 4;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int v = lane + 64 * u, j = v & 1, pix = (v >> 1) & 31, i = v >> 6;
+                            if (pix >= wvalid) continue;
+                            const float* sp = (const float*)(scr + pix * SP_EPITCH) + 2 * i + j;
+                            float o[8];
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) {
+                                const float q = sp[4 * t];
+                                o[t] = !has_act ? q : (is_relu ? fmaxf(q, 0.f) : fmaxf(q, q * slope));
+                            }
+                            float* yp = a.y + (((size_t)bb * a.H * 2 + 2 * gy + i) * ((size_t)a.W * 2) + 2 * (x0 + pix) + j) * Cq +
+                                        (n0 + 32 * n) / 4;
+                            *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
+                            *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                        }
                     }
                 }
                 DASR_WAVE_SYNC();
@@ -269,7 +306,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
 //   ws[mode][slice][tap][chunk][piece j][row r][16],  element kk of row r at half (kk >> 3) ^ ((r >> 3) & 1)
 //   mode 0 (forward): rows = output channels, K = input channels:  w[tap][16 chunk + kk][slice * NTILE + r]
 //   mode 1 (dgrad):   rows = input channels,  K = output channels: w[8 - tap][slice * NTILE + r][16 chunk + kk]
-__host__ __device__ static inline int sp_ntile(int N) { return (N % 128) == 0 ? 128 : 64; }
+__host__ __device__ static inline int sp_ntile(int N) { return (N % 128) == 0 ? 128 : ((N % 64) == 0 ? 64 : 32); }
 __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__ w, bf16_t* __restrict__ ws, int Cin, int Cout) {
     const size_t per_mode = (size_t)27 * Cin * Cout;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < 2 * (size_t)9 * Cin * Cout; idx += (size_t)gridDim.x * 256) {
@@ -300,7 +337,7 @@ __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------ C ABI
 static bool sp_ok(int H, int W, int K, int N) {
-    return H > 0 && W > 0 && (K % 16) == 0 && (N % 64) == 0 && N <= 1024 && (size_t)H * W * (K > N ? K : N) * 4 < ((size_t)1 << 31);
+    return H > 0 && W > 0 && (K % 16) == 0 && (N % 32) == 0 && N <= 1024 && (size_t)H * W * (K > N ? K : N) * 4 < ((size_t)1 << 31);
 }
 extern "C" int dasr_conv3x3_split_supported(int H, int W, int Cin, int Cout) {
     return (sp_ok(H, W, Cin, Cout) && sp_ok(H, W, Cout, Cin)) ? 1 : 0;      // forward and dgrad
@@ -311,12 +348,12 @@ extern "C" size_t dasr_conv3x3_split_weights_bytes(int Cin, int Cout) {
 }
 extern "C" int dasr_conv3x3_split_weights(const float* w_packed, unsigned short* w_split, int Cin, int Cout, void* stream) {
     DASR_CHECK_PTR(w_packed); DASR_CHECK_PTR(w_split);
-    DASR_CHECK_SHAPE(Cin > 0 && Cout > 0 && (Cin % 64) == 0 && (Cout % 64) == 0);
+    DASR_CHECK_SHAPE(Cin > 0 && Cout > 0 && (Cin % 32) == 0 && (Cout % 32) == 0);
     DASR_LAUNCH(k_split_weights, dim3(dasr_ew_grid((size_t)18 * Cin * Cout)), dim3(256), 0, stream, w_packed, (bf16_t*)w_split, Cin, Cout);
     DASR_RETURN_LAUNCH_STATUS();
 }
 static int sp_launch(ConvSplitArgs& a, void* stream) {
-    const int NT = (a.Cout % 128) == 0 ? 4 : 2;
+    const int NT = sp_ntile(a.Cout) / 32;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + SP_TH - 1) / SP_TH;
     a.nsl = a.Cout / (32 * NT);
@@ -326,16 +363,21 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
     if ((dasr_get_conv_bf16_impl() & 3) == 2) a.G8 = 1;        // tests: one workgroup per XCD walks every item of it
     const size_t lds = 2 * (size_t)SP_HBYTES + 3 * (size_t)(3 * 32 * NT * 32) + sizeof(float) * (size_t)a.Cout;
     const dim3 grid(8 * a.G8);
-    if (NT == 4) DASR_LAUNCH((k_conv3x3_split<4>), grid, dim3(SP_NTHR), lds, stream, a);
-    else         DASR_LAUNCH((k_conv3x3_split<2>), grid, dim3(SP_NTHR), lds, stream, a);
+    if (NT == 4)      DASR_LAUNCH((k_conv3x3_split<4>), grid, dim3(SP_NTHR), lds, stream, a);
+    else if (NT == 2) DASR_LAUNCH((k_conv3x3_split<2>), grid, dim3(SP_NTHR), lds, stream, a);
+    else              DASR_LAUNCH((k_conv3x3_split<1>), grid, dim3(SP_NTHR), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
 }
-extern "C" int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const float* bias, float* y, int B, int H,
-                                      int W, int Cin, int Cout, void* stream) {
+extern "C" int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const float* bias,
+                                      const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int act,
+                                      int ps_r, void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(w_split); DASR_CHECK_PTR(y);
     DASR_CHECK_SHAPE(B > 0);
     if (!dasr_conv3x3_split_supported(H, W, Cin, Cout)) return DASR_E_UNSUPPORTED;
-    ConvSplitArgs a{x, (const bf16_t*)w_split, bias, y, B, H, W, Cin, Cout, 0, 0, 0, 0, 0, 0, 0};
+    if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
+    if (ps_r < 1) ps_r = 1;
+    if (ps_r > 2 || (ps_r == 2 && (residual != nullptr || (Cout % 128) != 0))) return DASR_E_UNSUPPORTED;
+    ConvSplitArgs a{x, (const bf16_t*)w_split, bias, residual, y, B, H, W, Cin, Cout, 0, act, ps_r, 0, 0, 0, 0, 0, 0};
     return sp_launch(a, stream);
 }
 // dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * w[tap][ci][co]: mode 1 of the split image (taps already flipped)
@@ -344,8 +386,8 @@ extern "C" int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short
     DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(w_split); DASR_CHECK_PTR(dx);
     DASR_CHECK_SHAPE(B > 0);
     if (!dasr_conv3x3_split_supported(H, W, Cin, Cout)) return DASR_E_UNSUPPORTED;
-    ConvSplitArgs a{dconv, (const bf16_t*)w_split + (size_t)27 * Cin * Cout, nullptr, dx, B, H, W, Cout, Cin, accumulate,
-                    0, 0, 0, 0, 0, 0};
+    ConvSplitArgs a{dconv, (const bf16_t*)w_split + (size_t)27 * Cin * Cout, nullptr, nullptr, dx, B, H, W, Cout, Cin,
+                    accumulate, DASR_ACT_NONE, 1, 0, 0, 0, 0, 0, 0};
     return sp_launch(a, stream);
 }
 

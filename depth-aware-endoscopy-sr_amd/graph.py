@@ -162,13 +162,15 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
         # the InstanceNorm statistics of the output come out of the convolution's epilogue (no second pass over y)
         y, mean, var = ops.conv2d_fwd_stats(x.data, w.data, bias.data if bias is not None else None)
         stats = (mean, var)
-    elif (SPLIT_BF16 and f32 and w.data.dtype == torch.float32 and act == ops.ACT_NONE and ps_r == 1 and residual is None
-          and stride == 1 and pad == 1 and not transposed and tuple(w.data.shape[1:3]) == (3, 3)
+    elif (SPLIT_BF16 and f32 and w.data.dtype == torch.float32 and stride == 1 and pad == 1 and not transposed
+          and tuple(w.data.shape[1:3]) == (3, 3)
+          and (ps_r == 1 or (ps_r == 2 and residual is None and w.data.shape[4] % 128 == 0))
           and x.data.shape[0] * x.data.shape[1] * x.data.shape[2] >= SPLIT_MIN_PIXELS
           and ops.conv3x3_split_supported(x.data.shape[1], x.data.shape[2], w.data.shape[3], w.data.shape[4])):
         if w.split is None:
             w.split = ops.conv3x3_split_weights(w.data)
-        y = ops.conv3x3_fwd_split(x.data, w.split, bias.data if bias is not None else None, w.data.shape[4])
+        y = ops.conv3x3_fwd_split(x.data, w.split, bias.data if bias is not None else None, w.data.shape[4],
+                                  residual.data if residual is not None else None, act, ps_r)
     else:
         y = ops.conv2d_fwd(x.data, w.data, bias.data if bias is not None else None,
                            residual.data if residual is not None else None, stride, pad, transposed, act, ps_r, out_dtype)
@@ -212,7 +214,7 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             ws = _side_stream(dconv.device, "wgrad") if (WGRAD_STREAM and dconv.is_cuda) else None
             if ws is None and side_wgrad and TAIL_WGRAD_SIDE and SIDE_STREAM and dconv.is_cuda:
                 ws = _side_stream(dconv.device)       # the depth-branch stream: idle while the HR tail runs backward
-            if ws is None and w.split is not None and SPLIT_WGRAD:
+            if ws is None and w.split is not None and SPLIT_WGRAD and Cin % 64 == 0 and Cout % 64 == 0:
                 dw, db = ops.conv3x3_wgrad_split(x.data, dconv, want_bias=bias is not None)
             elif ws is None:
                 dw, db = ops.conv2d_wgrad(x.data, dconv, wshape, stride, pad, transposed, want_bias=bias is not None)

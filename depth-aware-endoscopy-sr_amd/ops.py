@@ -399,10 +399,13 @@ def conv3x3_split_weights(w):
     return ws
 
 
-def conv3x3_fwd_split(x, ws, bias, Cout):
+def conv3x3_fwd_split(x, ws, bias, Cout, residual=None, act=ACT_NONE, ps_r=1):
     B, H, W, Cin = x.shape
-    y = empty((B, H, W, Cout), x)
-    _call("dasr_conv3x3_fwd_split", _p(x), _pa(ws), _p(bias, True), _p(y), B, H, W, Cin, Cout)
+    if ps_r > 1:
+        y = empty((B, H * ps_r, W * ps_r, Cout // (ps_r * ps_r)), x)
+    else:
+        y = empty((B, H, W, Cout), x)
+    _call("dasr_conv3x3_fwd_split", _p(x), _pa(ws), _p(bias, True), _p(residual, True), _p(y), B, H, W, Cin, Cout, act, ps_r)
     return y
 
 

@@ -146,18 +146,19 @@ int dasr_conv2d_wgrad_act(const float* x, const float* dy, const float* y, float
  * (normalization.py:41-42,73-74) and the DGB convolutions (sftmd_arch.py:811-820): every fp32 operand is the exact sum
  * of three bf16 pieces, six bf16 MFMAs per product term give the fp32 product to 2^-26, accumulated in fp32 - the
  * accuracy of the exact-fp32 MFMA kernels at 6/16 of their matrix time.  Replaces the same nn.Conv2d calls as
- * dasr_conv2d_fwd / dasr_conv2d_dgrad; both need Cin % 64 == 0, Cout % 64 == 0.
+ * dasr_conv2d_fwd / dasr_conv2d_dgrad / dasr_conv2d_wgrad; Cin % 32 == 0, Cout % 32 == 0 (wgrad: % 64).
  *   split_weights: the fp32 packed kernel [2][3][3][Cin][Cout] -> a bf16 image (split_weights_bytes) holding, for the
  *                  forward and the dgrad, the three pieces of every K-step's slice contiguously (once per step)
- *   fwd_split:     y = conv(x, w) + bias            x [B,H,W,Cin], y [B,H,W,Cout] fp32
+ *   fwd_split:     y = act(conv(x, w) + bias + residual), optionally stored through PixelShuffle(2) (then no residual,
+ *                  Cout % 128 == 0)                 x [B,H,W,Cin], y [B,H,W,Cout] fp32
  *   dgrad_split:   dx (+)= conv^T(dconv, w)         dconv [B,H,W,Cout], dx [B,H,W,Cin] fp32
  *   wgrad_split:   dw_hwio [3][3][Cin][Cout] = sum_pixels x (x) dconv, dbias (may be NULL) = sum dconv; workspace:
  *                  dasr_conv3x3_wgrad_split_workspace() bytes (replaces dasr_conv2d_wgrad for these layers) */
 int dasr_conv3x3_split_supported(int H, int W, int Cin, int Cout);
 size_t dasr_conv3x3_split_weights_bytes(int Cin, int Cout);
 int dasr_conv3x3_split_weights(const float* w_packed, unsigned short* w_split, int Cin, int Cout, void* stream);
-int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const float* bias, float* y, int B, int H, int W,
-                           int Cin, int Cout, void* stream);
+int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const float* bias, const float* residual, float* y,
+                           int B, int H, int W, int Cin, int Cout, int act, int ps_r, void* stream);
 int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short* w_split, float* dx, int accumulate, int B, int H,
                              int W, int Cin, int Cout, void* stream);
 size_t dasr_conv3x3_wgrad_split_workspace(int B, int H, int W, int Cin, int Cout);

@@ -1137,6 +1137,42 @@ def check_split_conv(device, seed=5):
                 assert g_acc <= fac * g_32 + 2 * slack, ("dgrad accumulate", cin, cout, g_acc)
                 out["%d->%d %dx%d%s" % (cin, cout, H, W, {0: "", 2: " 1wg"}[mode])] = tuple(
                     float("%.3g" % v) for v in (e_sp, e_32, g_sp, g_32, g_acc, w_sp, w_32))
+            # fused epilogues and the 32-channel tile (the HR tail: classic blocks, upscale convs): act, residual, PixelShuffle(2)
+            eshapes = [(32, 32, 1, True, 1, 1, 17, 35), (64, 32, 2, False, 1, 2, 9, 40), (32, 128, 2, False, 2, 1, 10, 33),
+                       (64, 256, 2, False, 2, 1, 16, 32)]
+            if device == "cpu":
+                eshapes = eshapes[:3] if mode == 0 else eshapes[2:3]
+            for (cin, cout, act, res, ps, B, H, W) in eshapes:
+                x = rn(B, cin, H, W)
+                w = rn(cout, cin, 3, 3) * (1.0 / math.sqrt(9 * cin))
+                bias = rn(cout) * 0.3
+                r = rn(B, cout, H, W) if res else None
+                ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+                if ps > 1:
+                    ref = F.pixel_shuffle(ref, ps)
+                if res:
+                    ref = ref + r.double()
+                ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.2) if act == 2 else ref)
+                xd = nhwc(x).to(device)
+                wp = ops.pack_hwio(w.permute(2, 3, 1, 0).contiguous().to(device))
+                ws = ops.conv3x3_split_weights(wp)
+                rd = nhwc(r).to(device) if res else None
+                y_sp = ops.conv3x3_fwd_split(xd, ws, bias.to(device), cout, rd, act, ps)
+                y_32 = ops.conv2d_fwd(xd, wp, bias.to(device), rd, 1, 1, False, act, ps)
+                assert tuple(y_sp.shape) == tuple(y_32.shape) == tuple(nhwc(ref).shape)
+                e_sp = (nchw(y_sp.cpu()).double() - ref).abs().max().item() / ref.abs().max().item()
+                e_32 = (nchw(y_32.cpu()).double() - ref).abs().max().item() / ref.abs().max().item()
+                assert e_sp <= fac * e_32 + slack, ("fwd epilogue", cin, cout, act, res, ps, e_sp, e_32)
+                dy = rn(B, cout, H, W)
+                gx64, = torch.autograd.grad(F.conv2d(x.double().requires_grad_(True), w.double(), None, padding=1),
+                                            [], dy.double(), allow_unused=True) if False else (None,)
+                x64 = x.double().requires_grad_(True)
+                gx64, = torch.autograd.grad(F.conv2d(x64, w.double(), None, padding=1), x64, dy.double())
+                dx_sp = ops.conv3x3_dgrad_split(nhwc(dy).to(device), ws, xd.shape)
+                g_sp = (nchw(dx_sp.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
+                assert g_sp <= 4e-6, ("dgrad 32-channel", cin, cout, g_sp)
+                out["%d->%d act%d res%d ps%d%s" % (cin, cout, act, res, ps, {0: "", 2: " 1wg"}[mode])] = (
+                    float("%.3g" % e_sp), float("%.3g" % e_32), float("%.3g" % g_sp))
         finally:
             ops.set_conv_bf16_impl(0)
     return out
