@@ -401,7 +401,11 @@ extern "C" int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short
 // apart), 38 conflict-free ds_read_b32, splits them in registers and issues 9 taps x 6 products = 54 bf16 MFMAs - against
 // 8 x 9 = 72 exact-fp32 MFMAs of twice the duration each for the same 16 pixels.
 #define SW_TW 32
-#define SW_TH 2
+// A workgroup owns a (32 MT) x (32 NTW) block of (ci, co).  With four (ci-tile, co-tile) pairs every wave takes one; blocks with
+// fewer pairs (32-channel layers of the HR tail) give each pair G = 4 / pairs waves, which split the K-STEPS of a tile (every
+// wave keeps all nine taps: the three taps of a kernel row share one 10-pixel window) and add their accumulators through
+// LDS at the end.  Tile rows by pairs, so that a tile always holds the same amount of matrix work and ~50-76 KB of LDS.
+__host__ __device__ constexpr int sw_th(int MT, int NTW) { return MT * NTW == 4 ? 2 : (MT * NTW == 2 ? 4 : 8); }
 
 struct SplitWgradArgs {
     const float* x;      // [B,H,W,Cin]
@@ -422,14 +426,17 @@ __device__ __forceinline__ void sp_split_pair(float v0, float v1, bf16x2_t& h0, 
     h2 = dasr_f2bf2(r0 - dasr_bf2f(h1[0]), r1 - dasr_bf2f(h1[1]));
 }
 
+template <int MT, int NTW>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a) {
     DASR_DYN_SMEM(smem);
-    constexpr int CIG = 64, COG = 64, TH = SW_TH, HW = SW_TW + 2;
+    constexpr int CIG = 32 * MT, COG = 32 * NTW, TH = sw_th(MT, NTW), HW = SW_TW + 2;
+    constexpr int PAIRS = MT * NTW, G = 4 / PAIRS;
     float* sX = (float*)smem;                                   // [(TH+2)*HW][CIG]
     float* sD = sX + (TH + 2) * HW * CIG;                       // [TH*TW][COG]
     const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
     const int li = lane & 31, lh = lane >> 5;
-    const int mt = wv >> 1, nt = wv & 1;
+    const int pair = wv % PAIRS, grp = wv / PAIRS;              // (wave-uniform: branches around MFMAs below)
+    const int mt = pair / NTW, nt = pair % NTW;
     const int cgroups = a.Cout / COG;
     const int ci0 = (blockIdx.x / cgroups) * CIG, co0 = (blockIdx.x % cgroups) * COG;
     const int tiles_x = (a.W + SW_TW - 1) / SW_TW, tiles_y = (a.H + TH - 1) / TH;
@@ -450,10 +457,10 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int x0 = tx * SW_TW, y0 = ty * TH;
         // stage the tile: every global load of a thread before the first LDS write (see k_conv3x3_wgrad_mfma)
-        constexpr int NX = (TH + 2) * HW * (CIG / 4), NXI = (NX + 255) / 256;        // 2176 float4 pieces: 9 per thread
-        constexpr int ND = TH * SW_TW * (COG / 4), NDI = (ND + 255) / 256;           // 1024: 4 per thread
+        constexpr int NX = (TH + 2) * HW * (CIG / 4), NXI = (NX + 255) / 256;        // 64 x 64 block: 2176 float4 pieces, 9 per thread
+        constexpr int ND = TH * SW_TW * (COG / 4), NDI = (ND + 255) / 256;           //                1024: 4 per thread
         // (144 accumulator registers are resident: the x pieces go in two batches, the second one after the barrier)
-        constexpr int XA = 4;
+        constexpr int XA = NDI >= 8 ? 1 : (8 - NDI < NXI ? 8 - NDI : NXI);
         float4 vx[NXI - XA > XA ? NXI - XA : XA], vd[NDI];
         auto ldx = [&](int u) {
             const int idx = tid + 256 * u;
@@ -476,7 +483,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
             const int c4 = idx % (COG / 4), pix = idx / (COG / 4);
             const int gy = y0 + pix / SW_TW, gx = x0 + pix % SW_TW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < a.H && gx < a.W)
+            if (idx < ND && gy < a.H && gx < a.W)
                 v = *(const float4*)(a.dy + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * c4);
             vd[u] = v;
         }
@@ -486,7 +493,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
 #pragma unroll
         for (int u = 0; u < NDI; ++u) {
             const int idx = tid + 256 * u;
-            *(float4*)(sD + (idx / (COG / 4)) * COG + 4 * (idx % (COG / 4))) = vd[u];
+            if (idx < ND) *(float4*)(sD + (idx / (COG / 4)) * COG + 4 * (idx % (COG / 4))) = vd[u];
         }
 #pragma unroll
         for (int u = XA; u < NXI; ++u) vx[u - XA] = ldx(u);
@@ -498,7 +505,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
             for (int px = 0; px < TH * SW_TW; ++px) bsum += sD[px * COG + tid];
         }
 #pragma unroll 1
-        for (int s = 0; s < TH * 2; ++s) {
+        for (int s = grp; s < TH * 2; s += G) {
             const int py = s >> 1, pc = 16 * (s & 1) + 8 * lh;       // this lane's first pixel column of the K-step
             // dconv operand: 8 pixels of channel co0 + 32 nt + li
             bf16x8 B0, B1, B2;
@@ -544,8 +551,31 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
             }
         }
     }
+    if (G > 1) {
+        // waves grp = 1 .. G-1 hand their accumulators to wave grp = 0 of the same pair, one tap at a time through
+        // (G - 1) * PAIRS * 4 KB of the (now idle) staging LDS
+        float* sR = (float*)smem;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            __syncthreads();
+            if (grp > 0) {
+                float* q = sR + ((grp - 1) * PAIRS + pair) * 1024 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q[64 * r] = acc[t][r];
+            }
+            __syncthreads();
+            if (grp == 0) {
+                for (int gg = 0; gg < G - 1; ++gg) {
+                    const float* q = sR + (gg * PAIRS + pair) * 1024 + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += q[64 * r];
+                }
+            }
+        }
+    }
     if (do_bias) a.bslabs[(size_t)blockIdx.y * a.Cout + co0 + tid] = bsum;
     float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
+    if (grp != 0) return;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
@@ -556,27 +586,31 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
     }
 }
 
-static void sw_plan(int B, int H, int W, int Cin, int Cout, int& groups, int& ntiles, int& P) {
-    groups = (Cin / 64) * (Cout / 64);
-    ntiles = B * ((H + SW_TH - 1) / SW_TH) * ((W + SW_TW - 1) / SW_TW);
+static void sw_plan(int B, int H, int W, int Cin, int Cout, int& MT, int& NTW, int& groups, int& ntiles, int& P) {
+    MT = (Cin % 64) == 0 ? 2 : 1;
+    NTW = (Cout % 64) == 0 ? 2 : 1;
+    if (MT == 1 && (Cout % 128) == 0) NTW = 4;      // 32 input channels x a multiple of 128 outputs: four pairs again
+    groups = (Cin / (32 * MT)) * (Cout / (32 * NTW));
+    const int th = sw_th(MT, NTW);
+    ntiles = B * ((H + th - 1) / th) * ((W + SW_TW - 1) / SW_TW);
     P = 512 / groups;
     if (P < 1) P = 1;
     if (P > ntiles) P = ntiles;
 }
 extern "C" size_t dasr_conv3x3_wgrad_split_workspace(int B, int H, int W, int Cin, int Cout) {
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 64)) return 0;
-    int groups, ntiles, P;
-    sw_plan(B, H, W, Cin, Cout, groups, ntiles, P);
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 32) || (Cout % 32)) return 0;
+    int MT, NTW, groups, ntiles, P;
+    sw_plan(B, H, W, Cin, Cout, MT, NTW, groups, ntiles, P);
     return sizeof(float) * ((size_t)P * 9 * Cin * Cout + (size_t)P * Cout);
 }
 extern "C" int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
                                         size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(dw); DASR_CHECK_PTR(workspace);
     DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0);
-    if ((Cin % 64) != 0 || (Cout % 64) != 0) return DASR_E_UNSUPPORTED;
+    if ((Cin % 32) != 0 || (Cout % 32) != 0) return DASR_E_UNSUPPORTED;
     if (workspace_bytes < dasr_conv3x3_wgrad_split_workspace(B, H, W, Cin, Cout)) return DASR_E_WORKSPACE;
-    int groups, ntiles, P;
-    sw_plan(B, H, W, Cin, Cout, groups, ntiles, P);
+    int MT, NTW, groups, ntiles, P;
+    sw_plan(B, H, W, Cin, Cout, MT, NTW, groups, ntiles, P);
     const size_t nW = (size_t)9 * Cin * Cout;
     float* slabs = (float*)workspace;
     float* bslabs = dbias ? slabs + (size_t)P * nW : nullptr;
@@ -585,7 +619,13 @@ extern "C" int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, floa
     int ysplit = 1;
     while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
     SplitWgradArgs a{x, dconv, slabs, bslabs, ysplit > 1 ? dw : nullptr, ysplit > 1 ? nW : 0, B, H, W, Cin, Cout, P, ntiles};
-    const size_t lds = sizeof(float) * (size_t)((SW_TH + 2) * (SW_TW + 2) * 64 + SW_TH * SW_TW * 64);
-    DASR_LAUNCH(k_conv3x3_wgrad_split, dim3(groups, P), dim3(256), lds, stream, a);
+    const int th = sw_th(MT, NTW);
+    const size_t lds = sizeof(float) * (size_t)((th + 2) * (SW_TW + 2) * 32 * MT + th * SW_TW * 32 * NTW);
+    const dim3 grid(groups, P);
+    if (MT == 2 && NTW == 2)      DASR_LAUNCH((k_conv3x3_wgrad_split<2, 2>), grid, dim3(256), lds, stream, a);
+    else if (MT == 1 && NTW == 4) DASR_LAUNCH((k_conv3x3_wgrad_split<1, 4>), grid, dim3(256), lds, stream, a);
+    else if (MT == 2 && NTW == 1) DASR_LAUNCH((k_conv3x3_wgrad_split<2, 1>), grid, dim3(256), lds, stream, a);
+    else if (MT == 1 && NTW == 2) DASR_LAUNCH((k_conv3x3_wgrad_split<1, 2>), grid, dim3(256), lds, stream, a);
+    else                          DASR_LAUNCH((k_conv3x3_wgrad_split<1, 1>), grid, dim3(256), lds, stream, a);
     return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit > 1, bslabs, dbias, Cout);
 }

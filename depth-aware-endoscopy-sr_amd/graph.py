@@ -214,7 +214,7 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             ws = _side_stream(dconv.device, "wgrad") if (WGRAD_STREAM and dconv.is_cuda) else None
             if ws is None and side_wgrad and TAIL_WGRAD_SIDE and SIDE_STREAM and dconv.is_cuda:
                 ws = _side_stream(dconv.device)       # the depth-branch stream: idle while the HR tail runs backward
-            if ws is None and w.split is not None and SPLIT_WGRAD and Cin % 64 == 0 and Cout % 64 == 0:
+            if ws is None and w.split is not None and SPLIT_WGRAD:
                 dw, db = ops.conv3x3_wgrad_split(x.data, dconv, want_bias=bias is not None)
             elif ws is None:
                 dw, db = ops.conv2d_wgrad(x.data, dconv, wshape, stride, pad, transposed, want_bias=bias is not None)

@@ -146,7 +146,7 @@ int dasr_conv2d_wgrad_act(const float* x, const float* dy, const float* y, float
  * (normalization.py:41-42,73-74) and the DGB convolutions (sftmd_arch.py:811-820): every fp32 operand is the exact sum
  * of three bf16 pieces, six bf16 MFMAs per product term give the fp32 product to 2^-26, accumulated in fp32 - the
  * accuracy of the exact-fp32 MFMA kernels at 6/16 of their matrix time.  Replaces the same nn.Conv2d calls as
- * dasr_conv2d_fwd / dasr_conv2d_dgrad / dasr_conv2d_wgrad; Cin % 32 == 0, Cout % 32 == 0 (wgrad: % 64).
+ * dasr_conv2d_fwd / dasr_conv2d_dgrad / dasr_conv2d_wgrad; Cin % 32 == 0, Cout % 32 == 0.
  *   split_weights: the fp32 packed kernel [2][3][3][Cin][Cout] -> a bf16 image (split_weights_bytes) holding, for the
  *                  forward and the dgrad, the three pieces of every K-step's slice contiguously (once per step)
  *   fwd_split:     y = act(conv(x, w) + bias + residual), optionally stored through PixelShuffle(2) (then no residual,

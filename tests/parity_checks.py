@@ -1171,6 +1171,14 @@ def check_split_conv(device, seed=5):
                 dx_sp = ops.conv3x3_dgrad_split(nhwc(dy).to(device), ws, xd.shape)
                 g_sp = (nchw(dx_sp.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
                 assert g_sp <= 4e-6, ("dgrad 32-channel", cin, cout, g_sp)
+                # weight gradient of the smaller (ci, co) blocks: 32 x 32, 64 x 32, 32 x 128 (waves split the K-steps)
+                w64 = w.double().requires_grad_(True)
+                gw64, = torch.autograd.grad(F.conv2d(x.double(), w64, None, padding=1), w64, dy.double())
+                dw_sp, db_sp = ops.conv3x3_wgrad_split(xd, nhwc(dy).to(device))
+                dw_32, _ = ops.conv2d_wgrad(xd, nhwc(dy).to(device), (3, 3, cin, cout))
+                w_sp, w_32 = rel_max(dw_sp.permute(3, 2, 0, 1), gw64), rel_max(dw_32.permute(3, 2, 0, 1), gw64)
+                assert w_sp <= fac * w_32 + slack, ("wgrad small block", cin, cout, w_sp, w_32)
+                assert rel_max(db_sp, dy.double().sum((0, 2, 3))) <= 2e-6
                 out["%d->%d act%d res%d ps%d%s" % (cin, cout, act, res, ps, {0: "", 2: " 1wg"}[mode])] = (
                     float("%.3g" % e_sp), float("%.3g" % e_32), float("%.3g" % g_sp))
         finally:
