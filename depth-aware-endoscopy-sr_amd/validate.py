@@ -36,31 +36,29 @@ def calculate_psnr(img1, img2):
     return 20 * math.log10(255.0 / math.sqrt(mse))
 
 
-def _gaussian_window(window_size, channel, like):
-    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)],
+def _window_1d(window_size=11, sigma=1.5):
+    """The reference's 1-D Gaussian, built the way pytorch_ssim builds it (fp32 tensor, normalised in fp32)."""
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)],
                      dtype=torch.float32)
-    g = (g / g.sum()).unsqueeze(1)
-    w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
-    return w2.expand(channel, 1, window_size, window_size).contiguous().to(like.device).type_as(like)
+    return g / g.sum()
 
 
 def ssim(img1, img2, window_size=11, size_average=True):
     """pytorch_ssim.ssim (pytorch_ssim/__init__.py:17-37,65-73): 11x11 Gaussian (sigma 1.5) windows, zero padding,
-    C1 = 0.01^2, C2 = 0.03^2 on [0,1] images; `[B,C,H,W]` tensors on any device."""
-    channel = img1.shape[1]
-    window = _gaussian_window(window_size, channel, img1)
-    pad = window_size // 2
-    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
-    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
-    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
-    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
-    if size_average:
-        return ssim_map.mean()
-    return ssim_map.mean(1).mean(1).mean(1)
+    C1 = 0.01^2, C2 = 0.03^2 on [0,1] images `[B,C,H,W]` - one HIP kernel pass over both images (dasr_ssim: the five
+    windowed moments, the SSIM ratio and its mean), no torch compute ops."""
+    import ctypes
+    from . import _lib, ops
+    if window_size != 11:
+        raise NotImplementedError("dasr_amd.validate.ssim: the reference's 11 x 11 window only")
+    a, b = img1.contiguous().float(), img2.contiguous().float()
+    B, C, H, W = a.shape
+    out = torch.empty((B,), dtype=torch.float32, device=a.device)
+    nbytes = int(_lib.get().dasr_ssim_workspace(B, C, H, W))
+    ws = torch.empty((max(1, nbytes // 4),), dtype=torch.float32, device=a.device)
+    g = (ctypes.c_float * 11)(*[float(v) for v in _window_1d()])
+    ops._call("dasr_ssim", ops._p(a), ops._p(b), ctypes.cast(g, ctypes.c_void_p), ops._p(out), ops._p(ws), nbytes, B, C, H, W)
+    return out.mean() if size_average else out
 
 
 @torch.no_grad()

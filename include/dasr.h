@@ -368,6 +368,15 @@ int dasr_weight_expand_t2_bf16(const float* w_hwio, const float* bias, unsigned 
 int dasr_weight_collapse_t2(const float* dw_expanded, const float* dbias_expanded, float* dw_hwio, float* dbias, int Cin,
                             int Cout, void* stream);
 
+/* ---- SSIM (validation metric) -------------------------------------------------------------------------------------
+ * pytorch_ssim.ssim (reference codes/pytorch_ssim/__init__.py:17-37,65-73; train.py:239): 11 x 11 Gaussian windows
+ * (sigma 1.5, zero padding), C1 = 0.01^2, C2 = 0.03^2, images [B,C,H,W] fp32 in [0,1].  One pass over both images:
+ * out_per_sample[b] = mean over (C,H,W) of the SSIM map (their mean over b is size_average=True).  window11: HOST
+ * pointer to the eleven normalised 1-D window weights.  workspace: dasr_ssim_workspace() bytes. */
+size_t dasr_ssim_workspace(int B, int C, int H, int W);
+int dasr_ssim(const float* img1, const float* img2, const float* window11, float* out_per_sample, void* workspace,
+              size_t workspace_bytes, int B, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -345,3 +345,25 @@ def psnr_255(a, b):
     if mse == 0:
         return float("inf")
     return 20.0 * math.log10(255.0 / math.sqrt(mse))
+
+
+# ---- SSIM (validation metric): CPU restatement of pytorch_ssim/__init__.py:7-37 as written (2-D window = g g^T, five grouped
+# convolutions), the checker for dasr_ssim; pinned by tests/golden/ssim.npz (generated from the reference's own module)
+def ssim_ref(img1, img2, window_size=11, size_average=True):
+    import math as _math
+    g = torch.tensor([_math.exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)],
+                     dtype=torch.float32)
+    g = (g / g.sum()).unsqueeze(1)
+    channel = img1.shape[1]
+    window = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0).expand(channel, 1, window_size, window_size).contiguous()
+    window = window.to(img1.device).type_as(img1)
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
+    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)

@@ -670,11 +670,36 @@ def check_validation_and_folding(device):
     ps = ss = 0.0
     for lq, gt, dm, mk in frames:
         o = O.depthnet_forward(sd, cfg, lq.cpu(), dm.cpu(), mk.cpu())
-        ss += float(validate.ssim(o, gt.cpu()))
+        ss += float(O.ssim_ref(o, gt.cpu()))
         a, b = validate.tensor2img(o[0]) / 255.0, validate.tensor2img(gt[0]) / 255.0
         ps += validate.calculate_psnr(a[4:-4, 4:-4] * 255, b[4:-4, 4:-4] * 255)
-    assert n == 2 and abs(psnr - ps / 2) <= 1e-2 and abs(ssim_v - ss / 2) <= 1e-5, (psnr, ps / 2, ssim_v, ss / 2)
+    assert n == 2 and abs(psnr - ps / 2) <= 1e-2 and abs(ssim_v - ss / 2) <= 2e-5, (psnr, ps / 2, ssim_v, ss / 2)
     return dict(psnr=psnr, ssim=ssim_v, folded=n_folded)
+
+
+def check_ssim_kernel(device):
+    """dasr_ssim (one HIP pass: windowed moments + SSIM ratio + mean) against the REFERENCE's pytorch_ssim values
+    (tests/golden/ssim.npz, 2e-6) and against the CPU restatement on frames with ragged tiles / more samples (2e-6)."""
+    from dasr_amd import validate
+    from tests.golden_cases import ssim_inputs
+    g = np.load(os.path.join(GOLDEN, "ssim.npz"))
+    worst = 0.0
+    for name, (a, b) in ssim_inputs().items():
+        ad, bd = a.to(device), b.to(device)
+        m = float(validate.ssim(ad, bd))
+        per = validate.ssim(ad, bd, size_average=False).cpu().numpy()
+        worst = max(worst, abs(m - float(g[name + ".mean"])), float(np.abs(per - g[name + ".per_image"]).max()))
+        assert abs(m - float(g[name + ".mean"])) <= 2e-6 and np.abs(per - g[name + ".per_image"]).max() <= 2e-6, name
+    gen = torch.Generator().manual_seed(9)
+    for (B, C, H, W) in [(3, 3, 45, 70), (1, 1, 7, 9), (2, 3, 64, 96)]:
+        a = torch.rand(B, C, H, W, generator=gen)
+        b = (a + 0.1 * torch.randn(B, C, H, W, generator=gen)).clamp(0, 1)
+        got = validate.ssim(a.to(device), b.to(device), size_average=False).cpu()
+        want = O.ssim_ref(a, b, size_average=False)
+        d = (got - want).abs().max().item()
+        worst = max(worst, d)
+        assert d <= 2e-6, ((B, C, H, W), d)
+    return dict(worst=worst)
 
 
 def check_checkpoint_interop(device, tmpdir):

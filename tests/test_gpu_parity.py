@@ -32,6 +32,10 @@ def test_split_conv():
     print(pc.check_split_conv("cuda"))
 
 
+def test_ssim_kernel():
+    print(pc.check_ssim_kernel("cuda"))
+
+
 def test_graphed_trainer_matches_eager():
     """harness.Trainer(use_graph=True): three eager steps, one captured, then replays - against the eager trainer on the same
     batches (which change every step: the loader's tensors are copied into the captured ones, region bytes included).

@@ -15,13 +15,19 @@ from tests.golden_cases import ssim_inputs
 from tests import parity_checks as pc
 
 
-def test_ssim_matches_reference(golden_dir):
+def test_ssim_oracle_matches_reference(golden_dir):
+    """The CPU restatement (oracle.ssim_ref) against the reference's own pytorch_ssim values."""
+    from oracle import depthnet_oracle as O
     g = np.load(os.path.join(golden_dir, "ssim.npz"))
     for name, (a, b) in ssim_inputs().items():
-        assert abs(float(validate.ssim(a, b)) - float(g[name + ".mean"])) <= 2e-6, name
-        per = validate.ssim(a, b, size_average=False).numpy()
+        assert abs(float(O.ssim_ref(a, b)) - float(g[name + ".mean"])) <= 2e-6, name
+        per = O.ssim_ref(a, b, size_average=False).numpy()
         assert np.abs(per - g[name + ".per_image"]).max() <= 2e-6, name
     assert abs(float(g["identical.mean"]) - 1.0) <= 1e-6
+
+
+def test_ssim_kernel_matches_reference(emu):  # noqa: F811
+    print(pc.check_ssim_kernel("cpu"))
 
 
 def test_tensor2img_and_psnr():
