@@ -488,8 +488,14 @@ __device__ __forceinline__ void sean_gather_folded(const float* sD, const unsign
 // two barriers are covered by loads in flight.
 struct SeanTile { int b, y0, x0; };
 
+// Residual variant: one more operand in flight per pixel group.  Under the 168-register budget of three workgroups per CU it
+// spilled (8.4 MB of scratch writes per launch at B = 16); with 256 registers and TWO workgroups per CU (the launch then deals
+// its tiles over 512 slots) it does not: 144.5 -> 138 us at B = 32, 72.1 -> 70.9 us at B = 16 (A/B on one MI355X, round 3).
+#ifndef DASR_SEAN_RES_OCC
+#define DASR_SEAN_RES_OCC 2
+#endif
 template <bool RELU, bool HAS_RES, typename TA>
-__global__ void __launch_bounds__(256, 3) k_sean_fwd_onehot(SeanGeom g, const TA* __restrict__ t,
+__global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_fwd_onehot(SeanGeom g, const TA* __restrict__ t,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ var,
                                                             const TA* __restrict__ gb2,
@@ -1027,7 +1033,7 @@ static int sean_fwd_impl(const T* t, const float* mean, const float* var, const 
     if (fast) {
         int tiles = B * ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
         int slices = (int)dasr_cdiv(C, 64);
-        int nwg = 768 / slices;                             // 256 CUs x 3 resident workgroups (51 KB of LDS each)
+        int nwg = (residual ? 256 * DASR_SEAN_RES_OCC : 768) / slices;   // 256 CUs x 3 (2) resident workgroups (51 KB of LDS each)
         if (nwg < 1) nwg = 1;
         if (nwg > tiles) nwg = tiles;
         const int per = ((tiles / nwg) << 16) | (tiles % nwg);      // (base, rem), see the kernel; rem < nwg <= 768
