@@ -73,6 +73,10 @@ def block_plan(cfg):
 # flow back through them - so that the bf16 kernels can be compared against it tightly instead of only through a
 # PSNR budget.  Off by default: every golden-vector test runs the plain fp32 / fp64 graph.
 _BF16_STORAGE = False
+# study switches (tools/bf16_model_study.py): tensors the model keeps in fp32 although the HIP path stores them in bf16 -
+# "block_out" (the residual stream: every block's output), "conv_out" (the DGB conv outputs that feed the instance norms),
+# "gb2" (gamma_o / beta_o).  Empty = the shipping configuration.
+BF16_KEEP_FP32 = set()
 
 
 class _RoundBf16(torch.autograd.Function):
@@ -85,8 +89,10 @@ class _RoundBf16(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
-def _r(x):
+def _r(x, tag=None):
     """An activation tensor that the bf16 path keeps in HBM."""
+    if tag is not None and tag in BF16_KEEP_FP32:
+        return x
     return _RoundBf16.apply(x) if _BF16_STORAGE else x
 
 
@@ -163,8 +169,8 @@ def sean(sd, prefix, x, depth_map, depth_mask, st, cfg):
     depth_map = F.interpolate(depth_map, size=x.size()[2:], mode="nearest")    # :58
     depth_mask = F.interpolate(depth_mask, size=x.size()[2:], mode="nearest")  # :59
     actv = _r(F.relu(plain_conv(sd, prefix + ".mlp_mask.0", depth_map)))       # :61
-    beta_o = _r(plain_conv(sd, prefix + ".mlp_beta_o", actv, trunk=True))      # :73
-    gamma_o = _r(plain_conv(sd, prefix + ".mlp_gamma_o", actv, trunk=True))    # :74
+    beta_o = _r(plain_conv(sd, prefix + ".mlp_beta_o", actv, trunk=True), "gb2")      # :73
+    gamma_o = _r(plain_conv(sd, prefix + ".mlp_gamma_o", actv, trunk=True), "gb2")    # :74
     st = F.conv2d(st.unsqueeze(3), sd[prefix + ".A_i_j.weight"], sd[prefix + ".A_i_j.bias"])  # :80
     st = st.expand(st.size(0), st.size(1), st.size(2), depth_mask.size(3)).permute(0, 3, 2, 1)  # :81
     style_map = st.matmul(depth_mask.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)                   # :82
@@ -182,16 +188,16 @@ def sean(sd, prefix, x, depth_map, depth_mask, st, cfg):
 def depth_block(sd, name, x, depth_map, depth_mask, st, cfg):
     """Depth_Residual_Block_Mask.forward (sftmd_arch.py:826-834); conv1/conv2 are
     ``Sequential(Conv2d, InstanceNorm2d(affine=False))`` (:811-820)."""
-    t = F.instance_norm(_r(plain_conv(sd, name + ".conv1.0", x, trunk=True)), eps=1e-5)
+    t = F.instance_norm(_r(plain_conv(sd, name + ".conv1.0", x, trunk=True), "conv_out"), eps=1e-5)
     a = _r(F.relu(sean(sd, name + ".norm1", t, depth_map, depth_mask, st, cfg)))
-    t = F.instance_norm(_r(plain_conv(sd, name + ".conv2.0", a, trunk=True)), eps=1e-5)
-    return _r(F.relu(x + sean(sd, name + ".norm2", t, depth_map, depth_mask, st, cfg)))
+    t = F.instance_norm(_r(plain_conv(sd, name + ".conv2.0", a, trunk=True), "conv_out"), eps=1e-5)
+    return _r(F.relu(x + sean(sd, name + ".norm2", t, depth_map, depth_mask, st, cfg)), "block_out")
 
 
 def classic_block(sd, name, x):
     """Classic_Residual_Block.forward, weight-norm variant (sftmd_arch.py:131-151)."""
     f = wn_conv(sd, name + ".block.2", _r(F.relu(wn_conv(sd, name + ".block.0", x, trunk=True))), trunk=True)
-    return _r(F.relu(x + f))
+    return _r(F.relu(x + f), "block_out")
 
 
 def upscale(sd, name, x, r, second_conv):

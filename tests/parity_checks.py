@@ -1638,8 +1638,16 @@ def check_bf16_c3_full_frame(device="cuda", scale=4, H=256, W=320):
     sd = _oracle_sd(net)
     with torch.no_grad():
         ref = O.depthnet_forward(sd, cfg, lq, dm, mk)
-        with O.bf16_storage():                      # CPU model of the same rounding points (oracle, test infrastructure)
-            ref_model = O.depthnet_forward(sd, cfg, lq, dm, mk)
+    # CPU model of the same rounding points (oracle.bf16_storage, test infrastructure): its image AND its harness-loss
+    # gradients - the bf16 kernels are gated against the model of what they are supposed to compute, not only against this
+    # repo's own fp32 run
+    sdm = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    wm = torch.ones(10, requires_grad=True)
+    with O.bf16_storage():
+        ref_model_g = O.depthnet_forward(sdm, cfg, lq, dm, mk)
+        O.total_loss(ref_model_g, gt, mk, wm)[0].backward()
+    ref_model = ref_model_g.detach()
+    model_grads = {k: v.grad for k, v in sdm.items() if v.grad is not None}
     psnr_model = O.psnr_255(ref_model, ref)
     lqd, gtd, dmd, mkd = [t.to(device) for t in (lq, gt, dm, mk)]
     res = {}
@@ -1669,7 +1677,19 @@ def check_bf16_c3_full_frame(device="cuda", scale=4, H=256, W=320):
         dot += (a * b).sum().item()
         nb += b.pow(2).sum().item()
     rel, cos = math.sqrt(num / den), dot / math.sqrt(den * nb)
-    out = dict(dpsnr_fp32=dpsnr32, dpsnr_bf16=dpsnr16, psnr_bf16_vs_oracle=psnr16, psnr_cpu_bf16_model_vs_oracle=psnr_model,
+    # HIP bf16 gradients against the model's (and, for scale, the model's against the fp32 HIP run)
+    def _dist(ga, gb):
+        n_ = d_ = t_ = m_ = 0.0
+        for k, a in ga.items():
+            if any(z in k for z in ZERO_GRAD_KEYS) or k not in gb:
+                continue
+            a, b = a.double().cpu(), gb[k].double().cpu()
+            n_ += (a - b).pow(2).sum().item(); d_ += a.pow(2).sum().item()
+            t_ += (a * b).sum().item(); m_ += b.pow(2).sum().item()
+        return math.sqrt(n_ / d_), t_ / math.sqrt(d_ * m_)
+    rel_m, cos_m = _dist(model_grads, res[BF16][3])
+    rel_mf, cos_mf = _dist(res[torch.float32][3], model_grads)
+    out = dict(grad_hip_bf16_vs_model=(rel_m, cos_m), grad_model_vs_fp32=(rel_mf, cos_mf), dpsnr_fp32=dpsnr32, dpsnr_bf16=dpsnr16, psnr_bf16_vs_oracle=psnr16, psnr_cpu_bf16_model_vs_oracle=psnr_model,
                max_err_bf16=(sr16 - ref).abs().max().item(), loss_grad_rel_l2_bf16_vs_fp32=rel, loss_grad_cosine=cos,
                l_pix=(res[torch.float32][1], res[BF16][1]), l_dyn=(res[torch.float32][2], res[BF16][2]))
     print("bf16 full frame x%d %dx%d:" % (scale, H, W), out)
