@@ -1641,7 +1641,7 @@ def check_bf16_c3_full_frame(device="cuda", scale=4, H=256, W=320):
     # CPU model of the same rounding points (oracle.bf16_storage, test infrastructure): its image AND its harness-loss
     # gradients - the bf16 kernels are gated against the model of what they are supposed to compute, not only against this
     # repo's own fp32 run
-    sdm = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    sdm = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
     wm = torch.ones(10, requires_grad=True)
     with O.bf16_storage():
         ref_model_g = O.depthnet_forward(sdm, cfg, lq, dm, mk)
@@ -1703,6 +1703,11 @@ def check_bf16_c3_full_frame(device="cuda", scale=4, H=256, W=320):
     # points (oracle.bf16_storage) lands within 3 dB of the HIP path's distance to the fp32 image
     assert psnr16 >= psnr_model - 3.0, (psnr16, psnr_model)
     assert rel <= BF16_C3_GRAD_GATE[0] and cos >= BF16_C3_GRAD_GATE[1], (rel, cos)
+    # against the CPU model of the same rounding points: measured on the MI355X rel-L2 0.226 / cosine 0.9747 at c3's frame,
+    # 0.115 / 0.9934 at c4's - CLOSER than the model itself sits to the fp32 gradient (0.271 / 0.9626 and 0.145 / 0.9897:
+    # thirteen double-instance-norm blocks amplify any two roundings apart); gates ~2.2x the measured distances
+    gate_m = (0.5, 0.94) if scale == 4 else (0.3, 0.98)
+    assert rel_m <= gate_m[0] and cos_m >= gate_m[1], ("bf16 gradients vs the bf16 model", rel_m, cos_m)
     return out
 
 
