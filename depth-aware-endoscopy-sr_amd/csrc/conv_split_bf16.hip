@@ -302,6 +302,228 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     sp_wait_vm<0>();
 }
 
+// ---- 32 produced channels (the HR tail: 32 -> 32, 64 -> 32, and the dgrads of 32 -> 32 / 32 -> 128).  With one 32-channel tile a
+// wave has only 12 MFMAs per (tap, 16-channel) step, and a barrier per step costs as much as the step (681 us average
+// against ~420 us of matrix time on the x8 bench's fourteen launches).  The kernel slices of a chunk are tiny here (9 taps x
+// 3 KB), so ALL NINE are fetched with the halo chunk, double-buffered by chunk: one wait + barrier per CHUNK (108 MFMAs per
+// wave), the nine taps run free of synchronisation and the compiler pipelines reads, splits and MFMAs across them.
+__global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int NT = 1, NTILE = 32, PIECE = NTILE * 32, SLAB = 3 * PIECE;   // 3 KB per (tap, chunk)
+    constexpr int WCH = 9 * SLAB, WPC = WCH / 16;                              // a chunk's nine slices: 27 KB = 1728 DMA pieces
+    char* const sH = smem;                              // [2][SP_HBYTES]
+    char* const sW = smem + 2 * SP_HBYTES;              // [2][WCH]
+    float* const sBias = (float*)(sW + 2 * WCH);        // [Cout]
+    const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
+    const int li = lane & 31, lh = lane >> 5;
+    const dasr_lds_addr_t ldsH = DASR_LDS_ADDR(sH) + 1024 * wv, ldsW = DASR_LDS_ADDR(sW) + 1024 * wv;
+
+    const int xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3;
+    const int ibeg = xcd * a.Q;
+    const int iend = ibeg + a.Q < a.nitems ? ibeg + a.Q : a.nitems;
+    int item = ibeg + jwg;
+    if (item >= iend) return;
+    const int NC = a.Cin >> 4;
+    const int pixb = a.Cin * 4, rowb = a.W * pixb;
+    const size_t sampb = (size_t)a.H * rowb;
+    const char* const zp = (const char*)sp_zero_page;
+
+    for (int i = tid; i < a.Cout; i += SP_NTHR) sBias[i] = a.bias ? a.bias[i] : 0.f;
+    __syncthreads();
+
+    int x0, y0, n0, bb;
+    auto decode = [&](int it, int& ox0, int& oy0, int& on0, int& ob) {
+        const int ns = it % a.nsl, pt = it / a.nsl;
+        const int tile = pt % (a.tiles_x * a.tiles_y);
+        ob = pt / (a.tiles_x * a.tiles_y);
+        ox0 = (tile % a.tiles_x) * 32;
+        oy0 = (tile / a.tiles_x) * SP_TH;
+        on0 = ns * NTILE;
+    };
+    decode(item, x0, y0, n0, bb);
+    int hoff[SP_NHP];
+    unsigned hok = 0;
+    const char* hxb;
+    auto halo_setup = [&](int fx0, int fy0, int fb, bool real) {
+        hxb = (const char*)a.x + (size_t)fb * sampb;
+        const int org = (fy0 - 1) * rowb + (fx0 - 1) * pixb;
+        int t = tid;
+#ifndef DASR_HIPEMU
+        asm volatile("" : "+v"(t));
+#endif
+        hok = 0;
+#pragma unroll
+        for (int u = 0; u < SP_NHP; ++u) {
+            const int P = (t >> 2) + (SP_NTHR / 4) * u;
+            const int pr = P / SP_HW, pc = P - pr * SP_HW;
+            hoff[u] = org + pr * rowb + pc * pixb + 16 * ((t & 3) ^ ((P >> 2) & 3));
+            const bool ok = real && P < SP_HPIX && (unsigned)(fy0 - 1 + pr) < (unsigned)a.H && (unsigned)(fx0 - 1 + pc) < (unsigned)a.W;
+            hok |= ok ? (1u << u) : 0u;
+        }
+    };
+    // everything chunk cc of (the item whose halo state is set up, slice fn0) needs: 5 halo pieces + the nine kernel slices
+    // (pieces p = tid + 512 u < 1728: tap p / 192, 16-byte piece p % 192 of that tap's slice; waves 0-2 carry a fourth)
+    auto chunk_issue = [&](int cc, int fn0, int buf) {
+#pragma unroll
+        for (int u = 0; u < SP_NHP; ++u) {
+            const char* src = ((hok >> u) & 1u) ? hxb + hoff[u] + 64 * cc : zp;
+            DASR_GLDS16(src, ldsH + buf * SP_HBYTES + 1024 * SP_NWV * u);
+        }
+        const char* wsrc = (const char*)a.ws + (size_t)(((fn0 / NTILE) * 9) * NC + cc) * SLAB;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = tid + SP_NTHR * u;
+            if (u == 3 && wv >= 3) break;                       // (wave-uniform) 1728 = 3 x 512 + 192
+            const int tap = p / 192, q = p - tap * 192;
+            DASR_GLDS16(wsrc + (size_t)tap * NC * SLAB + 16 * q, ldsW + buf * WCH + 1024 * SP_NWV * u);
+        }
+    };
+
+    const int Pl = 2 * wv * SP_HW + li;
+    const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4);
+
+    int par = 0;
+    halo_setup(x0, y0, bb, true);
+    chunk_issue(0, n0, 0);
+
+    for (;;) {
+        const int nitem = item + a.G8;
+        const bool has_next = nitem < iend;
+        int nx0 = x0, ny0 = y0, nn0 = n0, nb = bb;
+        if (has_next) decode(nitem, nx0, ny0, nn0, nb);
+
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *(const float4*)(sBias + n0 + 8 * g + 4 * lh);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m][0][4 * g] = bv.x; acc[m][0][4 * g + 1] = bv.y;
+                acc[m][0][4 * g + 2] = bv.z; acc[m][0][4 * g + 3] = bv.w;
+            }
+        }
+
+        for (int cc = 0; cc < NC; ++cc) {
+            const bool last = cc == NC - 1;
+            if (last) halo_setup(nx0, ny0, nb, has_next);
+            // this chunk's halo and slices were issued a whole chunk ago (or in the prologue): everything this wave has in
+            // flight is exactly that (plus the previous item's output stores)
+            sp_wait_vm<0>();
+            DASR_RAW_BARRIER();
+            chunk_issue(last ? 0 : cc + 1, last ? nn0 : n0, par ^ 1);
+            const char* const hb = sH + par * SP_HBYTES;
+            const char* const wc = sW + par * WCH + boff;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                int Pq = Pl;
+#ifndef DASR_HIPEMU
+                asm volatile("" : "+v"(Pq));
+#endif
+                bf16x8 A[2][3];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int P = Pq + (m + dy) * SP_HW + dx;
+                    const int key = (P >> 2) & 3;
+                    const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
+                    const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
+                    const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    sp_split3(xv, A[m][0], A[m][1], A[m][2]);
+                }
+                const char* const wb = wc + tap * SLAB;
+                const bf16x8 B0 = *(const bf16x8*)(wb);
+                const bf16x8 B1 = *(const bf16x8*)(wb + PIECE);
+                const bf16x8 B2 = *(const bf16x8*)(wb + 2 * PIECE);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2, A[m][0], acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A[m][1], acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][2], acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A[m][0], acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][1], acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][0], acc[m][0], 0, 0, 0);
+                }
+            }
+            par ^= 1;
+        }
+
+        // ---- epilogue: 32 channels per pass through [pixel][32 + 4] fp32, 32 bytes per lane out; residual, activation,
+        // accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue
+        DASR_RAW_BARRIER();
+        char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
+        const int wvalid = a.W - x0;
+        const bool is_relu = a.act == DASR_ACT_RELU;
+        const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
+        const bool has_act = a.act != DASR_ACT_NONE;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int gy = y0 + 2 * wv + m;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 pk = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+                    *(f32x4*)(scr + li * SP_EPITCH + (8 * g + 4 * lh) * 4) = pk;
+                }
+                DASR_WAVE_SYNC();
+                if (gy < a.H) {
+                    if (a.ps_r == 1) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int v = lane + 64 * u, pix = v >> 2, cg = v & 3;
+                            if (pix >= wvalid) continue;
+                            const float4 lo = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg);
+                            const float4 hi = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg + 16);
+                            float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                            const size_t idx = (((size_t)bb * a.H + gy) * a.W + x0 + pix) * a.Cout + n0 + 32 * n + 8 * cg;
+                            if (a.residual) {
+                                const float4 r0 = *(const float4*)(a.residual + idx), r1 = *(const float4*)(a.residual + idx + 4);
+                                o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w;
+                                o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
+                            }
+                            if (has_act) {
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) o[t] = is_relu ? fmaxf(o[t], 0.f) : fmaxf(o[t], o[t] * slope);
+                            }
+                            float* yp = a.y + idx;
+                            if (a.accumulate) {
+                                const float4 o0 = *(const float4*)yp, o1 = *(const float4*)(yp + 4);
+                                o[0] += o0.x; o[1] += o0.y; o[2] += o0.z; o[3] += o0.w;
+                                o[4] += o1.x; o[5] += o1.y; o[6] += o1.z; o[7] += o1.w;
+                            }
+                            *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
+                            *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                        }
+                    } else {
+                        // PixelShuffle(2): out[b, 2gy+i, 2gx+j, c] = conv[b, gy, gx, 4c + 2i + j]: 8 values of c per (pixel, sub-pixel)
+                        const int Cq = a.Cout / 4;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int v = lane + 64 * u, j = v & 1, pix = (v >> 1) & 31, i = v >> 6;
+                            if (pix >= wvalid) continue;
+                            const float* sp = (const float*)(scr + pix * SP_EPITCH) + 2 * i + j;
+                            float o[8];
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) {
+                                const float q = sp[4 * t];
+                                o[t] = !has_act ? q : (is_relu ? fmaxf(q, 0.f) : fmaxf(q, q * slope));
+                            }
+                            float* yp = a.y + (((size_t)bb * a.H * 2 + 2 * gy + i) * ((size_t)a.W * 2) + 2 * (x0 + pix) + j) * Cq +
+                                        (n0 + 32 * n) / 4;
+                            *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
+                            *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                        }
+                    }
+                }
+                DASR_WAVE_SYNC();
+            }
+        }
+        if (!has_next) break;
+        item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
+    }
+    sp_wait_vm<0>();
+}
+
 // ---- the kernel split: fp32 packed [2][9][Cin][Cout] (plane 0 = HWIO) -> bf16 image of both modes
 //   ws[mode][slice][tap][chunk][piece j][row r][16],  element kk of row r at half (kk >> 3) ^ ((r >> 3) & 1)
 //   mode 0 (forward): rows = output channels, K = input channels:  w[tap][16 chunk + kk][slice * NTILE + r]
@@ -361,11 +583,12 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
     a.Q = (a.nitems + 7) / 8;
     a.G8 = a.Q < 32 ? a.Q : 32;
     if ((dasr_get_conv_bf16_impl() & 3) == 2) a.G8 = 1;        // tests: one workgroup per XCD walks every item of it
-    const size_t lds = 2 * (size_t)SP_HBYTES + 3 * (size_t)(3 * 32 * NT * 32) + sizeof(float) * (size_t)a.Cout;
+    const size_t lds = 2 * (size_t)SP_HBYTES + (NT == 1 ? 2 * (size_t)(9 * 3 * 32 * 32) : 3 * (size_t)(3 * 32 * NT * 32)) +
+                       sizeof(float) * (size_t)a.Cout;
     const dim3 grid(8 * a.G8);
     if (NT == 4)      DASR_LAUNCH((k_conv3x3_split<4>), grid, dim3(SP_NTHR), lds, stream, a);
     else if (NT == 2) DASR_LAUNCH((k_conv3x3_split<2>), grid, dim3(SP_NTHR), lds, stream, a);
-    else              DASR_LAUNCH((k_conv3x3_split<1>), grid, dim3(SP_NTHR), lds, stream, a);
+    else              DASR_LAUNCH(k_conv3x3_split_n32, grid, dim3(SP_NTHR), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
 }
 extern "C" int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const float* bias,
