@@ -167,8 +167,8 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
           and (ps_r == 1 or (ps_r == 2 and residual is None and w.data.shape[4] % 128 == 0))
           and x.data.shape[0] * x.data.shape[1] * x.data.shape[2] >= SPLIT_MIN_PIXELS
           and ops.conv3x3_split_supported(x.data.shape[1], x.data.shape[2], w.data.shape[3], w.data.shape[4])):
-        if w.split is None:
-            w.split = ops.conv3x3_split_weights(w.data)
+        if w.split is None:           # (eval + no_grad: cached with the folded kernel it is derived from)
+            w.split = _folded(tape, ("split", "@%x" % w.data.data_ptr()), [w.data], lambda: ops.conv3x3_split_weights(w.data))
         y = ops.conv3x3_fwd_split(x.data, w.split, bias.data if bias is not None else None, w.data.shape[4],
                                   residual.data if residual is not None else None, act, ps_r)
     else:
@@ -322,7 +322,7 @@ def expand_s2(tape, wp):
     """fp32 packed kernel of a 3x3 stride-2 conv -> bf16 packed kernel of its stride-1 form on the space-to-depth image."""
     _, _, _, Cin, Cout = wp.data.shape
     # (eval + no_grad: wp.data is itself the cached folded kernel, so its identity / version key this second cache level)
-    out = Var(_folded(tape, ("s2", wp.data.data_ptr()), [wp.data], lambda: ops.weight_expand_s2(wp.data)), wp.requires_grad)
+    out = Var(_folded(tape, ("s2", "@%x" % wp.data.data_ptr()), [wp.data], lambda: ops.weight_expand_s2(wp.data)), wp.requires_grad)
 
     def bwd():
         if out.grad is None:
@@ -342,7 +342,7 @@ def expand_t2(tape, wp, bias):
     """fp32 packed kernel + bias of a 3x3 stride-2 ConvTranspose2d -> (bf16 packed kernel, bias) of the stride-1 convolution
     Cin -> 4 Cout whose PixelShuffle(2) it is."""
     _, _, _, Cin, Cout = wp.data.shape
-    w4, b4 = _folded(tape, ("t2", wp.data.data_ptr()), [wp.data] + ([bias.data] if bias is not None else []),
+    w4, b4 = _folded(tape, ("t2", "@%x" % wp.data.data_ptr()), [wp.data] + ([bias.data] if bias is not None else []),
                      lambda: ops.weight_expand_t2(wp.data, bias.data if bias is not None else None))
     wout = Var(w4, wp.requires_grad)
     bout = Var(b4, bias.requires_grad) if bias is not None else None
