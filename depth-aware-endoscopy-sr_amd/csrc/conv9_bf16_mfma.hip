@@ -33,92 +33,112 @@ struct Conv9BfArgs {
 
 // ------------------------------------------------------------------------------------------ forward
 // 512 threads: wave w owns tile row w (two 32-pixel M-tiles).  Input tile 16 rows x 64 columns x 32 channels.
+// Round 3: the workgroup is PERSISTENT (one per CU, 105 KB of LDS) - the kernel slice (36 KB of fp32 from L2, rounded and
+// re-laid) is staged ONCE instead of once per 8 x 56-pixel tile, and the loads of tile t + 1 are issued right after tile t
+// has been written to LDS, in flight during its 36 MFMAs per wave and its shift-add epilogue (before: 8.7 us per tile and
+// CU for 0.55 us of matrix work, every tile paying its own HBM round trip and weight restaging with nothing to overlap).
 __global__ void __launch_bounds__(512) k_conv9x9_fwd_bf16(Conv9BfArgs a) {
     DASR_DYN_SMEM(smem);
     constexpr int CKP = 40;                                        // 80-byte pixel stride: conflict-free ds_read_b128
-    bf16_t* sIn = (bf16_t*)smem;                                   // [16][64][CKP]   (later: P [8][64][PST] fp32)
-    bf16_t* sW = sIn + (Q_TH + 8) * Q_TQ * CKP;                    // [9 kh][32 n][CKP]
+    bf16_t* sIn = (bf16_t*)smem;                                   // [16][64][CKP]   (per tile, later: P [8][64][PST] fp32)
+    bf16_t* sW = sIn + (Q_TH + 8) * Q_TQ * CKP;                    // [Cin/32][9 kh][32 n][CKP]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int TWO = Q_TQ - 8;
-    const int tiles_x = (a.W + TWO - 1) / TWO;
-    const int x0 = (blockIdx.x % tiles_x) * TWO, y0 = (blockIdx.x / tiles_x) * Q_TH, b = blockIdx.y;
+    const int tiles_x = (a.W + TWO - 1) / TWO, tiles_y = (a.H + Q_TH - 1) / Q_TH;
+    const int total = tiles_x * tiles_y * a.B;
     const int NN = 9 * a.Cout;   // <= 27
-    const BufRsrc rx = dasr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.Cin, (size_t)a.H * a.W * a.Cin * sizeof(bf16_t));
-    constexpr int NPC = (Q_TH + 8) * Q_TQ * 4 / 512;               // 8 pieces of 16 bytes per thread
-    unsigned offx[NPC];
+    const int NCK = a.Cin / 32;
+    // kernel slices, once: sW[c][kh][n = kw*Cout+co][ci] (zero rows for n >= 9*Cout); all 18 loads of a thread first
+    for (int c = 0; c < NCK; ++c) {
+        float wq[18];
 #pragma unroll
-    for (int u = 0; u < NPC; ++u) {
-        const int idx = tid + 512 * u, pix = idx >> 2, q4 = idx & 3;
-        const int gy = y0 - 4 + pix / Q_TQ, gx = x0 - 4 + pix % Q_TQ;
-        offx[u] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                      ? (unsigned)(((gy * a.W + gx) * a.Cin + 8 * q4) * (int)sizeof(bf16_t)) : DASR_OOB;
+        for (int u = 0; u < 18; ++u) {
+            const int e = tid + 512 * u, ci = e & 31, n = (e >> 5) & 31, kh = e >> 10;
+            const int nn = n < NN ? n : 0, kw = nn / a.Cout, co = nn % a.Cout;
+            const float v = a.w[(((size_t)kh * 9 + kw) * a.Cin + 32 * c + ci) * a.Cout + co];
+            wq[u] = n < NN ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {
+            const int e = tid + 512 * u, ci = e & 31, n = (e >> 5) & 31, kh = e >> 10;
+            sW[((c * 9 + kh) * 32 + n) * CKP + ci] = dasr_f2bf(wq[u]);
+        }
     }
-    f32x16 acc[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    for (int c0 = 0; c0 < a.Cin; c0 += 32) {
-        q_u32x4 vin[NPC];
-#pragma unroll
-        for (int u = 0; u < NPC; ++u) vin[u] = dasr_buffer_load16(rx, offx[u] + (unsigned)c0 * (unsigned)sizeof(bf16_t));
-        __syncthreads();                                   // every wave is done with the previous chunk
+    constexpr int NPC = (Q_TH + 8) * Q_TQ * 4 / 512;               // 8 pieces of 16 bytes per thread
+    q_u32x4 vin[NPC];
+    // loads of (tile, 32-channel chunk c0): unconditional (a tile index past the end re-reads the last tile)
+    auto fetch = [&](int tile, int c0) {
+        const int b = tile / (tiles_x * tiles_y), tt = tile - b * (tiles_x * tiles_y);
+        const int x0 = (tt % tiles_x) * TWO, y0 = (tt / tiles_x) * Q_TH;
+        const BufRsrc rx = dasr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.Cin, (size_t)a.H * a.W * a.Cin * sizeof(bf16_t));
 #pragma unroll
         for (int u = 0; u < NPC; ++u) {
-            const int idx = tid + 512 * u;
-            *(q_u32x4*)(sIn + (idx >> 2) * CKP + 8 * (idx & 3)) = vin[u];
+            const int idx = tid + 512 * u, pix = idx >> 2, q4 = idx & 3;
+            const int gy = y0 - 4 + pix / Q_TQ, gx = x0 - 4 + pix % Q_TQ;
+            const unsigned off = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                                     ? (unsigned)(((gy * a.W + gx) * a.Cin + c0 + 8 * q4) * (int)sizeof(bf16_t)) : DASR_OOB;
+            vin[u] = dasr_buffer_load16(rx, off);
         }
-        // kernel slice: sW[kh][n = kw*Cout+co][ci] (zero rows for n >= 9*Cout); all 18 loads of a thread first
-        {
-            float wq[18];
-#pragma unroll
-            for (int u = 0; u < 18; ++u) {
-                const int e = tid + 512 * u, ci = e & 31, n = (e >> 5) & 31, kh = e >> 10;
-                const int nn = n < NN ? n : 0, kw = nn / a.Cout, co = nn % a.Cout;
-                const float v = a.w[(((size_t)kh * 9 + kw) * a.Cin + c0 + ci) * a.Cout + co];
-                wq[u] = n < NN ? v : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 18; ++u) {
-                const int e = tid + 512 * u, ci = e & 31, n = (e >> 5) & 31, kh = e >> 10;
-                sW[(kh * 32 + n) * CKP + ci] = dasr_f2bf(wq[u]);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kh = 0; kh < 9; ++kh)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const bf16x8 Bf = *(const bf16x8*)(sW + (kh * 32 + li) * CKP + 16 * q + 8 * lh);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const bf16x8 A = *(const bf16x8*)(sIn + ((wv + kh) * Q_TQ + 32 * m + li) * CKP + 16 * q + 8 * lh);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[m], 0, 0, 0);
-                }
-            }
-    }
-    __syncthreads();
-    float* sP = (float*)smem;   // [8][64][PST]
-    if (li < Q_PST) {
+    };
+    int tile = blockIdx.x;
+    if (tile < total) fetch(tile, 0);
+    for (; tile < total; tile += gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y), tt = tile - b * (tiles_x * tiles_y);
+        const int x0 = (tt % tiles_x) * TWO, y0 = (tt / tiles_x) * Q_TH;
+        f32x16 acc[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int qx = 32 * m + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                sP[(wv * Q_TQ + qx) * Q_PST + li] = acc[m][g];
-            }
-    }
-    __syncthreads();
-    const int nout = Q_TH * TWO * a.Cout;
-    float* y = (float*)a.out;
-    for (int idx = tid; idx < nout; idx += 512) {
-        const int co = idx % a.Cout, ox = (idx / a.Cout) % TWO, r = idx / (a.Cout * TWO);
-        const int gy = y0 + r, gx = x0 + ox;
-        if (gy >= a.H || gx >= a.W) continue;
-        float v = a.bias ? a.bias[co] : 0.f;
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        for (int c = 0; c < NCK; ++c) {
+            __syncthreads();                               // every wave is done with the previous chunk / tile (incl. its P image)
 #pragma unroll
-        for (int kw = 0; kw < 9; ++kw) v += sP[(r * Q_TQ + ox + kw) * Q_PST + kw * a.Cout + co];
-        y[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co] = v;
+            for (int u = 0; u < NPC; ++u) {
+                const int idx = tid + 512 * u;
+                *(q_u32x4*)(sIn + (idx >> 2) * CKP + 8 * (idx & 3)) = vin[u];
+            }
+            __syncthreads();
+            {                                              // next chunk of this tile, or the first chunk of the next tile
+                const bool lastc = c + 1 == NCK;
+                const int nt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;
+                fetch(lastc ? nt : tile, lastc ? 0 : 32 * (c + 1));
+            }
+            const bf16_t* sWc = sW + c * 9 * 32 * CKP;
+#pragma unroll
+            for (int kh = 0; kh < 9; ++kh)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bf16x8 Bf = *(const bf16x8*)(sWc + (kh * 32 + li) * CKP + 16 * q + 8 * lh);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const bf16x8 A = *(const bf16x8*)(sIn + ((wv + kh) * Q_TQ + 32 * m + li) * CKP + 16 * q + 8 * lh);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[m], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+        float* sP = (float*)smem;   // [8][64][PST]
+        if (li < Q_PST) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int qx = 32 * m + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                    sP[(wv * Q_TQ + qx) * Q_PST + li] = acc[m][g];
+                }
+        }
+        __syncthreads();
+        const int nout = Q_TH * TWO * a.Cout;
+        float* y = (float*)a.out;
+        for (int idx = tid; idx < nout; idx += 512) {
+            const int co = idx % a.Cout, ox = (idx / a.Cout) % TWO, r = idx / (a.Cout * TWO);
+            const int gy = y0 + r, gx = x0 + ox;
+            if (gy >= a.H || gx >= a.W) continue;
+            float v = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int kw = 0; kw < 9; ++kw) v += sP[(r * Q_TQ + ox + kw) * Q_PST + kw * a.Cout + co];
+            y[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co] = v;
+        }
     }
 }
 
@@ -161,8 +181,9 @@ __device__ __forceinline__ void q_build_E(const Conv9BfArgs& a, const float* sDy
 }
 
 // ------------------------------------------------------------------------------------------ dgrad
-// tile: 8 rows x 64 columns of dx pixels x 32 input channels (blockIdx.z selects the 32-channel slice); 512 threads,
-// wave w owns tile row w
+// tile: 8 rows x 64 columns of dx pixels x 32 input channels (blockIdx.y selects the 32-channel slice); 512 threads,
+// wave w owns tile row w.  Round 3: persistent like the forward - Wd is staged once per workgroup, the dy values of tile
+// t + 1 are in flight (registers) while tile t's E image is built, multiplied and stored.
 __global__ void __launch_bounds__(512) k_conv9x9_dgrad_bf16(Conv9BfArgs a) {
     DASR_DYN_SMEM(smem);
     constexpr int EST = 40;                                        // 80-byte pixel stride (conflict-free ds_read_b128)
@@ -170,12 +191,11 @@ __global__ void __launch_bounds__(512) k_conv9x9_dgrad_bf16(Conv9BfArgs a) {
     bf16_t* sW = sE + (Q_TH + 8) * Q_TQ * EST;                     // [9 kh][32 ci][EST]: Wd[kh][k'][ci], k' contiguous
     float* sDy = (float*)(sW + 9 * 32 * EST);                      // [16][DYW]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int tiles_x = (a.W + Q_TQ - 1) / Q_TQ;
-    const int x0 = (blockIdx.x % tiles_x) * Q_TQ, y0 = (blockIdx.x / tiles_x) * Q_TH, b = blockIdx.y;
-    const int n0 = blockIdx.z * 32;
+    const int tiles_x = (a.W + Q_TQ - 1) / Q_TQ, tiles_y = (a.H + Q_TH - 1) / Q_TH;
+    const int total = tiles_x * tiles_y * a.B;
+    const int n0 = blockIdx.y * 32;
     const int KK = 9 * a.Cout;
-    q_stage_dy<512>(a, sDy, b, y0, x0, tid);
-    {                                                              // Wd[kh][k'][ci] = w[kh][8 - k'/Cout][ci][k' % Cout]
+    {                                                              // Wd[kh][k'][ci] = w[kh][8 - k'/Cout][ci][k' % Cout], once
         float wq[18];
 #pragma unroll
         for (int u = 0; u < 18; ++u) {
@@ -190,40 +210,73 @@ __global__ void __launch_bounds__(512) k_conv9x9_dgrad_bf16(Conv9BfArgs a) {
             sW[(kh * 32 + ci) * EST + kp] = dasr_f2bf(wq[u]);
         }
     }
-    __syncthreads();
-    q_build_E<512, EST>(a, sDy, sE, tid);
-    __syncthreads();
-    f32x16 acc[2];
+    // the fp32 dy tile of a tile (rows y0-4 .. y0+11, columns x0-4 .. x0+67, Cout channels interleaved), as q_stage_dy
+    // stages it, split into its load and its store half
+    const int rowf = (Q_TQ + 8) * a.Cout;
+    constexpr int NDYE = (Q_TH + 8) * Q_DYW, NI = (NDYE + 511) / 512;
+    float vdy[NI];
+    auto fetch = [&](int tile) {
+        const int b = tile / (tiles_x * tiles_y), tt = tile - b * (tiles_x * tiles_y);
+        const int x0 = (tt % tiles_x) * Q_TQ, y0 = (tt / tiles_x) * Q_TH;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 9; ++kh)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const bf16x8 Bf = *(const bf16x8*)(sW + (kh * 32 + li) * EST + 16 * q + 8 * lh);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                // dy row of output row wv for this kh: wv - kh + 4 (+4 for the tile's first row y0-4) = wv - kh + 8
-                const bf16x8 A = *(const bf16x8*)(sE + ((wv - kh + 8) * Q_TQ + 32 * m + li) * EST + 16 * q + 8 * lh);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[m], 0, 0, 0);
-            }
+        for (int u = 0; u < NI; ++u) {
+            const int idx = tid + 512 * u;
+            const int f = idx % Q_DYW, ry = idx / Q_DYW;
+            const int gy = y0 - 4 + ry, gx = x0 - 4 + f / a.Cout, co = f % a.Cout;
+            const bool ok = idx < NDYE && f < rowf && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            // (clamped address, unconditional load: a predicated prefetch would make hipcc drain vmcnt(0))
+            const size_t o = ok ? (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co : 0;
+            const float v = a.dy[o];
+            vdy[u] = ok ? v : 0.f;
         }
-    bf16_t* dx = (bf16_t*)a.out;
-    const int gy = y0 + wv;
-    if (gy < a.H) {
+    };
+    int tile = blockIdx.x;
+    if (tile < total) fetch(tile);
+    for (; tile < total; tile += gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y), tt = tile - b * (tiles_x * tiles_y);
+        const int x0 = (tt % tiles_x) * Q_TQ, y0 = (tt / tiles_x) * Q_TH;
+        __syncthreads();                                           // every wave is done with the previous tile's E image
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int idx = tid + 512 * u;
+            if (idx < NDYE) sDy[idx] = vdy[u];
+        }
+        __syncthreads();
+        fetch(tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile);
+        q_build_E<512, EST>(a, sDy, sE, tid);
+        __syncthreads();
+        f32x16 acc[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int gx = x0 + 32 * m + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                if (gx >= a.W) continue;
-                const size_t o = (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + n0 + li;
-                float v = acc[m][g];
-                if (a.accumulate) v += dasr_bf2f(dx[o]);
-                dx[o] = dasr_f2bf(v);
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 9; ++kh)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bf16x8 Bf = *(const bf16x8*)(sW + (kh * 32 + li) * EST + 16 * q + 8 * lh);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    // dy row of output row wv for this kh: wv - kh + 4 (+4 for the tile's first row y0-4) = wv - kh + 8
+                    const bf16x8 A = *(const bf16x8*)(sE + ((wv - kh + 8) * Q_TQ + 32 * m + li) * EST + 16 * q + 8 * lh);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf, acc[m], 0, 0, 0);
+                }
             }
+        bf16_t* dx = (bf16_t*)a.out;
+        const int gy = y0 + wv;
+        if (gy < a.H) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int gx = x0 + 32 * m + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                    if (gx >= a.W) continue;
+                    const size_t o = (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + n0 + li;
+                    float v = acc[m][g];
+                    if (a.accumulate) v += dasr_bf2f(dx[o]);
+                    dx[o] = dasr_f2bf(v);
+                }
+        }
     }
 }
 
@@ -322,18 +375,20 @@ __global__ void __launch_bounds__(256) k_conv9_wgrad_reduce_bf16(const float* __
 int conv9_bf16_fwd(const ConvGeom& g, const bf16_t* x, const float* w, const float* bias, float* y, void* stream) {
     Conv9BfArgs a{x, w, bias, nullptr, y, g.B, g.H, g.W, g.Cin, g.Cout, 0, 0, 0};
     const int TWO = Q_TQ - 8;
-    const int tiles = ((g.W + TWO - 1) / TWO) * ((g.H + Q_TH - 1) / Q_TH);
-    size_t lds = sizeof(bf16_t) * (size_t)((Q_TH + 8) * Q_TQ * 40 + 9 * 32 * 40);
-    const size_t ldsP = sizeof(float) * (size_t)(Q_TH * Q_TQ * Q_PST);
-    if (ldsP > lds) lds = ldsP;
-    DASR_LAUNCH(k_conv9x9_fwd_bf16, dim3(tiles, g.B), dim3(512), lds, stream, a);
+    const int tiles = ((g.W + TWO - 1) / TWO) * ((g.H + Q_TH - 1) / Q_TH) * g.B;
+    const size_t lds = sizeof(bf16_t) * (size_t)((Q_TH + 8) * Q_TQ * 40 + (g.Cin / 32) * 9 * 32 * 40);   // (P image aliases the tile)
+    if (lds > 160 * 1024) return DASR_E_UNSUPPORTED;
+    const int cap = (dasr_get_conv_bf16_impl() & 3) == 2 ? 3 : 256;    // (impl 2, tests: long per-workgroup tile lists)
+    DASR_LAUNCH(k_conv9x9_fwd_bf16, dim3(tiles < cap ? tiles : cap), dim3(512), lds, stream, a);     // one persistent workgroup per CU
     DASR_RETURN_LAUNCH_STATUS();
 }
 int conv9_bf16_dgrad(const ConvGeom& g, const float* dconv, const float* w, bf16_t* dx, int accumulate, void* stream) {
     Conv9BfArgs a{nullptr, w, nullptr, dconv, dx, g.B, g.H, g.W, g.Cin, g.Cout, accumulate, 0, 0};
-    const int tiles = ((g.W + Q_TQ - 1) / Q_TQ) * ((g.H + Q_TH - 1) / Q_TH);
+    const int tiles = ((g.W + Q_TQ - 1) / Q_TQ) * ((g.H + Q_TH - 1) / Q_TH) * g.B;
     const size_t lds = sizeof(bf16_t) * (size_t)((Q_TH + 8) * Q_TQ * 40 + 9 * 32 * 40) + sizeof(float) * (size_t)((Q_TH + 8) * Q_DYW);
-    DASR_LAUNCH(k_conv9x9_dgrad_bf16, dim3(tiles, g.B, g.Cin / 32), dim3(512), lds, stream, a);
+    int per = 256 / (g.Cin / 32) > 0 ? 256 / (g.Cin / 32) : 1;               // persistent: one workgroup per CU over all slices
+    if ((dasr_get_conv_bf16_impl() & 3) == 2) per = 3;                       // (impl 2, tests: long per-workgroup tile lists)
+    DASR_LAUNCH(k_conv9x9_dgrad_bf16, dim3(tiles < per ? tiles : per, g.Cin / 32), dim3(512), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
 }
 static void conv9_bf16_wgrad_plan(const ConvGeom& g, int& ntiles, int& P) {

@@ -1120,7 +1120,7 @@ def check_split_conv(device, seed=5):
         ops.set_conv_bf16_impl(mode)
         shapes = [(64, 64, 1, 17, 35), (128, 128, 1, 16, 32), (128, 64, 2, 33, 40), (64, 256, 1, 9, 70)]
         if device == "cpu":           # the emulator runs ~50 M MAC/s: a subset that still covers every code path
-            shapes = {0: [(64, 64, 1, 17, 35), (128, 128, 1, 9, 20)], 2: [(64, 128, 2, 17, 33), (64, 64, 3, 17, 40)]}[mode]
+            shapes = {0: [(64, 64, 1, 17, 35), (128, 128, 1, 9, 20)], 2: [(64, 128, 2, 17, 33)]}[mode]
         try:
             for (cin, cout, B, H, W) in shapes:
                 x = rn(B, cin, H, W) * (1.0 + rn(B, cin, 1, 1).abs())
@@ -1166,7 +1166,7 @@ def check_split_conv(device, seed=5):
             eshapes = [(32, 32, 1, True, 1, 1, 17, 35), (64, 32, 2, False, 1, 2, 9, 40), (32, 128, 2, False, 2, 1, 10, 33),
                        (64, 256, 2, False, 2, 1, 16, 32)]
             if device == "cpu":
-                eshapes = eshapes[:3] if mode == 0 else eshapes[2:3]
+                eshapes = eshapes[:2] if mode == 0 else eshapes[2:3]
             for (cin, cout, act, res, ps, B, H, W) in eshapes:
                 x = rn(B, cin, H, W)
                 w = rn(cout, cin, 3, 3) * (1.0 / math.sqrt(9 * cin))
@@ -1576,7 +1576,10 @@ def check_bf16_ops_vs_fp32_kernels(device, seed=1):
     # ---- 9x9 output convolution on the bf16 matrix cores: bf16 x, the fp32 kernel and dy rounded to bf16 as MFMA
     # operands, fp32 accumulation, fp32 y / dw / db.  Reference: torch's fp32 convolution of the SAME rounded operands, so
     # only the accumulation order differs (and the final rounding of the bf16 dx); ragged tile rows / columns, two batches
-    for (B9, H9, W9) in ((1, 11, 70), (2, 19, 60)):
+    # (the forward / dgrad workgroups are persistent: the second pass caps the grid at 3 workgroups - impl 2 - so that each
+    # walks several tiles, incl. across the batch boundary, with the next tile's loads in flight)
+    for (B9, H9, W9, impl9) in ((1, 11, 70, 0), (2, 19, 60, 0), (2, 19, 60, 2)):
+        ops.set_conv_bf16_impl(impl9)
         x9 = _bf(rn(B9, H9, W9, 32))
         w9f = rn(9, 9, 32, 3) * 0.02
         w9 = ops.pack_hwio(dev(w9f))
@@ -1602,7 +1605,8 @@ def check_bf16_ops_vs_fp32_kernels(device, seed=1):
         e3 = rel_max(dw16.permute(3, 2, 0, 1), gw)
         e4 = rel_max(db16, dy9.sum((0, 1, 2)))                  # the bias gradient sums the fp32 dy
         assert e3 <= 1e-5 and e4 <= 1e-5, ("conv9 bf16 wgrad", e3, e4)
-        out["conv9_%dx%d" % (H9, W9)] = (e, e1, e2, e3)
+        out["conv9_%dx%d_impl%d" % (H9, W9, impl9)] = (e, e1, e2, e3)
+    ops.set_conv_bf16_impl(0)
     # ---- epilogue backward (activation and PixelShuffle), add, accumulate, casts
     for act, ps in ((1, 1), (2, 2), (2, 3)):
         Cq = 8

@@ -107,7 +107,8 @@ def test_region_shortcut_invalidation(emu):
     print(pc.check_region_shortcut_invalidation("cpu"))
 
 
-@pytest.mark.parametrize("impl", [0, 2 + 16, 2 + 32, 1], ids=["persistent", "4wave_1wg_per_xcd", "8wave_1wg_per_xcd", "first_kernel"])
+# (the 4-wave form with one workgroup per XCD - impl 2 + 16 - runs on the GPU only: the emulator needs ~40 s per parameter)
+@pytest.mark.parametrize("impl", [0, 2 + 32, 1], ids=["persistent", "8wave_1wg_per_xcd", "first_kernel"])
 def test_bf16_conv_variants(emu, impl):
     print(pc.check_bf16_conv_variants("cpu", impl=impl))
 
