@@ -37,6 +37,8 @@ def parse_args(argv=None):
                     help="capture the training step into one hipGraph (harness.Trainer(use_graph=True)).  auto = off: "
                          "measured on MI355X at c4 (x8, 16 frames, bf16) the replay of the ~2000-node two-stream graph is "
                          "no faster than eager launches (40.2 vs 38.8 ms/step: the step is GPU-bound, the host runs 6 ms ahead)")
+    ap.add_argument("--split-pieces", type=int, default=None, choices=(2, 3),
+                    help="A/B: 3 = three bf16 pieces / six products, 2 = two scaled fp16 pieces / three products (graph.SPLIT_PIECES)")
     ap.add_argument("--no-split", action="store_true",
                     help="A/B: fp32 path without the split-bf16 convolutions (graph.SPLIT_BF16 = False: exact-fp32 MFMA kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,30 +188,37 @@ class ConvTimer:
 
 
 class SplitTimer:
-    """HIP events around the launches of the fp32 path's dominant kernel - k_conv3x3_split<4> on the 128 -> 128
-    gamma_o | beta_o convolution, forward (dasr_conv3x3_fwd_split): fp32 convolution as six bf16 MFMA products."""
+    """HIP events around the launches of the fp32 path's dominant kernel - k_conv3x3_split<4, NP> on the 128 -> 128
+    gamma_o | beta_o convolution, forward: an fp32 convolution as NP-piece products on the 16-bit matrix cores
+    (dasr_conv3x3_fwd_split2: two fp16 pieces, three MFMA products per term; dasr_conv3x3_fwd_split: three bf16 pieces, six)."""
 
     def __init__(self):
         self.pairs = []
         self.enabled = False
+        self.products = None
 
     def install(self):
         from dasr_amd import graph as g
-        orig = ops.conv3x3_fwd_split
 
-        def timed(x, ws, bias, Cout, *a, **k):
-            if not (self.enabled and x.shape[3] == 128 and Cout == 128):
-                return orig(x, ws, bias, Cout, *a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(x, ws, bias, Cout, *a, **k)
-            e1.record()
-            B, H, W, _ = x.shape
-            self.pairs.append((e0, e1, 2.0 * 9 * 128 * 128 * B * H * W))
-            return out
+        def wrap(orig, products, xi, ci):
+            def timed(*a, **k):
+                x, Cout = a[xi], a[ci]
+                if not (self.enabled and x.shape[3] == 128 and Cout == 128):
+                    return orig(*a, **k)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig(*a, **k)
+                e1.record()
+                B, H, W, _ = x.shape
+                self.pairs.append((e0, e1, 2.0 * 9 * 128 * 128 * B * H * W))
+                self.products = products
+                return out
+            return timed
 
-        ops.conv3x3_fwd_split = timed
-        g.ops.conv3x3_fwd_split = timed
+        ops.conv3x3_fwd_split = wrap(ops.conv3x3_fwd_split, 6, 0, 3)          # (x, ws, bias, Cout, ...)
+        ops.conv3x3_fwd_split2 = wrap(ops.conv3x3_fwd_split2, 3, 0, 4)        # (x, xmax, ws, bias, Cout, ...)
+        g.ops.conv3x3_fwd_split = ops.conv3x3_fwd_split
+        g.ops.conv3x3_fwd_split2 = ops.conv3x3_fwd_split2
 
     def summary(self):
         if not self.pairs:
@@ -217,15 +226,18 @@ class SplitTimer:
         ms = [a.elapsed_time(b) for a, b, _ in self.pairs]
         avg_ms = sum(ms) / len(ms)
         fl = self.pairs[0][2]
-        bf16_tf = 6 * fl / (avg_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "k_conv3x3_split<4> (dasr_conv3x3_fwd_split: fp32 128->128 gamma_o|beta_o conv as six bf16 "
-                                           "MFMA products of three-piece operands, forward)",
-                "achieved": round(bf16_tf, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": round(bf16_tf / MFMA_BF16_PEAK_TFS, 4), "traffic": None, "launches_timed": len(ms),
-                "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_flops_per_launch": 6 * fl,
+        n = self.products
+        tf = n * fl / (avg_ms * 1e-3) / 1e12
+        what = ("two scaled fp16 pieces per operand, three fp16 MFMA products per term (dasr_conv3x3_fwd_split2)" if n == 3 else
+                "three bf16 pieces per operand, six bf16 MFMA products per term (dasr_conv3x3_fwd_split)")
+        return {"bound": "mfma", "kernel": "k_conv3x3_split<4,%d>: fp32 128->128 gamma_o|beta_o conv, forward - %s" % (3 if n == 6 else 2, what),
+                "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": round(tf / MFMA_BF16_PEAK_TFS, 4), "traffic": None, "launches_timed": len(ms),
+                "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_flops_per_launch": n * fl,
                 "fp32_equivalent_tflops": round(fl / (avg_ms * 1e-3) / 1e12, 1),
                 "measured": "HIP events on the launch stream, one extra un-overlapped step after the timed region; "
-                            "FLOPs = 6 bf16 products x 2*9*128*128 per pixel (the fp32-equivalent rate counts one)"}
+                            "FLOPs = %d 16-bit products x 2*9*128*128 per pixel (the fp32-equivalent rate counts one); peak = the "
+                            "dense bf16 / fp16 MFMA rate" % n}
 
 
 def mfma_roofline(net, args, B, elapsed, timer_conv, config):
@@ -380,6 +392,9 @@ def main():
     if args.no_split:
         from dasr_amd import graph as _graph_mod3
         _graph_mod3.SPLIT_BF16 = False
+    if args.split_pieces is not None:
+        from dasr_amd import graph as _graph_mod4
+        _graph_mod4.SPLIT_PIECES = args.split_pieces
     if args.serial:
         from dasr_amd import graph as _graph_mod
         _graph_mod.SIDE_STREAM = False

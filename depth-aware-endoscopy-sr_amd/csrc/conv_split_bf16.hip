@@ -22,8 +22,24 @@
 //     K-step's slice is one linear 12 KB (6 KB) LDS-DMA copy;
 //   * K-step = (tap, 16 channels): 2 rows x NT tiles x 6 products = 48 (24) MFMAs per wave, small pieces first;
 //   * fp32 output through the fp32 scratch path of the epilogue, 32 bytes per lane.
+//
+// Round 3, second scheme: TWO fp16 pieces, THREE products (template parameter NP = 2; NP = 3 is the scheme above).
+// fp16 carries 11 significant bits: with x0 = fp16(x), x1 = fp16(x - x0) the pair holds 22-23 of the 24 bits (the
+// representation is exact for three values in four and one fp32 ulp off for the fourth - 0.5 ulp RMS, the size of one
+// more fp32 rounding), and  x w = x0 w0 + (x0 w1 + x1 w0) + O(2^-24 |x w|).  Half the matrix work of the bf16 scheme and
+// HALF the roundings into the fp32 accumulator, which is where both schemes and the exact-fp32 MFMA lose their accuracy
+// (measured against float64: fp16 x 2 is the closest of the three, tests/parity_checks.py check_split_conv).  What fp16
+// lacks is range (5 exponent bits): every tensor is scaled by a power of two that puts its largest magnitude in
+// [2^14, 2^15) - dasr_absmax leaves the maximum in device memory, the kernels derive the scale from its exponent, nothing
+// goes through the host - so that x1 stays a normal number down to 2^-18 of the tensor's maximum and loses absolute, never
+// relative-to-the-sum, precision below (floor: 2^-40 of the maximum).  The result is multiplied by the exact inverse of
+// the two scales in the epilogue (bias added there).
 #include "bf16.h"
 #include "conv_kernels.h"
+
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 #define SP_HW 34
 #define SP_NWV 8
@@ -44,6 +60,8 @@ struct ConvSplitArgs {
     float* y;                // [B,H,W,Cout], or [B,2H,2W,Cout/4] with the PixelShuffle(2) store
     int B, H, W, Cin, Cout, accumulate, act, ps_r;
     int tiles_x, tiles_y, nsl, nitems, Q, G8;
+    const float* xmax;       // NP = 2: max |x| and max |w| in device memory (dasr_absmax); NP = 3: unused
+    const float* wmax;
 };
 
 template <int N>
@@ -68,20 +86,169 @@ __device__ __forceinline__ void sp_split3(const float (&x)[8], bf16x8& a0, bf16x
     }
 }
 
-template <int NT>
+// ---- the fp16 x 2 scheme: scale exponents.  A tensor whose largest magnitude is m (bits of a non-negative float) gets
+// the scale 2^k, k = 14 - floor(log2 m) clamped to [-60, 60] (m = 0: 2^60, harmless), so that m 2^k is in [2^14, 2^15).
+__host__ __device__ static inline int sp_scale_exp(float m) {
+    unsigned u;
+    memcpy(&u, &m, 4);
+    int k = 14 - ((int)((u >> 23) & 0xffu) - 127);
+    return k < -60 ? -60 : (k > 60 ? 60 : k);
+}
+__host__ __device__ static inline float sp_pow2(int k) {        // 2^k, |k| <= 126
+    const unsigned u = (unsigned)(127 + k) << 23;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// x s = a0 + a1 to 22-23 bits (a0 the fp16 rounding of x s, a1 of what a0 left)
+__device__ __forceinline__ void sp_split2(const float (&x)[8], float s, f16x8& a0, f16x8& a1) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const float v0 = x[e] * s, v1 = x[e + 1] * s;
+        const f16_t h0 = (f16_t)v0, g0 = (f16_t)v1;
+        a0[e] = h0; a0[e + 1] = g0;
+        a1[e] = (f16_t)(v0 - (float)h0); a1[e + 1] = (f16_t)(v1 - (float)g0);
+    }
+}
+// operand fragments of one 8-element K slice and the products of a (kernel, activation) fragment pair, smallest first
+template <int NP> struct SpFrag;
+template <> struct SpFrag<3> {
+    typedef bf16x8 type;
+    typedef bf16_t elem;
+    static __device__ __forceinline__ void split(const float (&x)[8], float, type (&a)[3]) { sp_split3(x, a[0], a[1], a[2]); }
+    static __device__ __forceinline__ f32x16 mma(const type (&w)[3], const type (&x)[3], f32x16 c) {
+        // x0 w2 + x1 w1 + x2 w0, then x0 w1 + x1 w0, then x0 w0
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], c, 0, 0, 0);
+        return c;
+    }
+};
+template <> struct SpFrag<2> {
+    typedef f16x8 type;
+    typedef f16_t elem;
+    static __device__ __forceinline__ void split(const float (&x)[8], float s, type (&a)[2]) { sp_split2(x, s, a[0], a[1]); }
+    static __device__ __forceinline__ f32x16 mma(const type (&w)[2], const type (&x)[2], f32x16 c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], x[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[0], c, 0, 0, 0);
+        return c;
+    }
+};
+// per-launch scale state of the fp16 scheme: the activation scale and the inverse of (activation scale x kernel scale)
+struct SpScale { float sx, inv; };
+template <int NP>
+__device__ __forceinline__ SpScale sp_scales(const float* xmax, const float* wmax) {
+    SpScale r = {1.f, 1.f};
+    if (NP == 2) {
+        const int kx = sp_scale_exp(*xmax), kw = sp_scale_exp(*wmax);
+        r.sx = sp_pow2(kx);
+        r.inv = sp_pow2(-(kx + kw));
+    }
+    return r;
+}
+
+// ---- epilogue of one item: 32 channels per pass through [pixel][32 + 4] fp32 of the wave's scratch, 32 bytes per lane out;
+// residual, activation, accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue.  NP = 2: the sums are in
+// scaled units - times inv (the exact inverse of the two scales), plus the bias.
+template <int NT, int NP>
+__device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][NT], const ConvSplitArgs& a, char* const scr, const float* sBias,
+                                            const float inv, const int x0, const int y0, const int n0, const int bb,
+                                            const int wv, const int lane, const int li, const int lh) {
+    const int wvalid = a.W - x0;
+    const bool is_relu = a.act == DASR_ACT_RELU;
+    const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
+    const bool has_act = a.act != DASR_ACT_NONE;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int gy = y0 + 2 * wv + m;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 pk = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+                *(f32x4*)(scr + li * SP_EPITCH + (8 * g + 4 * lh) * 4) = pk;
+            }
+            DASR_WAVE_SYNC();
+            if (gy < a.H) {
+                if (a.ps_r == 1) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int v = lane + 64 * u, pix = v >> 2, cg = v & 3;
+                        if (pix >= wvalid) continue;
+                        const float4 lo = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg);
+                        const float4 hi = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg + 16);
+                        float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        if (NP == 2) {
+                            const float* bp = sBias + n0 + 32 * n + 8 * cg;
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) o[t] = fmaf(o[t], inv, bp[t]);
+                        }
+                        const size_t idx = (((size_t)bb * a.H + gy) * a.W + x0 + pix) * a.Cout + n0 + 32 * n + 8 * cg;
+                        if (a.residual) {
+                            const float4 r0 = *(const float4*)(a.residual + idx), r1 = *(const float4*)(a.residual + idx + 4);
+                            o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w;
+                            o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
+                        }
+                        if (has_act) {
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) o[t] = is_relu ? fmaxf(o[t], 0.f) : fmaxf(o[t], o[t] * slope);
+                        }
+                        float* yp = a.y + idx;
+                        if (a.accumulate) {
+                            const float4 o0 = *(const float4*)yp, o1 = *(const float4*)(yp + 4);
+                            o[0] += o0.x; o[1] += o0.y; o[2] += o0.z; o[3] += o0.w;
+                            o[4] += o1.x; o[5] += o1.y; o[6] += o1.z; o[7] += o1.w;
+                        }
+                        *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
+                        *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                    }
+                } else {
+                    // PixelShuffle(2): out[b, 2gy+i, 2gx+j, c] = conv[b, gy, gx, 4c + 2i + j]: 8 values of c per (pixel, sub-pixel)
+                    const int Cq = a.Cout / 4;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int v = lane + 64 * u, j = v & 1, pix = (v >> 1) & 31, i = v >> 6;
+                        if (pix >= wvalid) continue;
+                        const float* sp = (const float*)(scr + pix * SP_EPITCH) + 2 * i + j;
+                        float o[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const float q = NP == 2 ? fmaf(sp[4 * t], inv, sBias[n0 + 32 * n + 4 * t + 2 * i + j]) : sp[4 * t];
+                            o[t] = !has_act ? q : (is_relu ? fmaxf(q, 0.f) : fmaxf(q, q * slope));
+                        }
+                        float* yp = a.y + (((size_t)bb * a.H * 2 + 2 * gy + i) * ((size_t)a.W * 2) + 2 * (x0 + pix) + j) * Cq +
+                                    (n0 + 32 * n) / 4;
+                        *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
+                        *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                    }
+                }
+            }
+            DASR_WAVE_SYNC();
+        }
+    }
+}
+
+template <int NT, int NP>
 __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     DASR_DYN_SMEM(smem);
-    constexpr int NTILE = 32 * NT, PIECE = NTILE * 32, SLAB = 3 * PIECE;     // bytes: one bf16 piece [NTILE][16], a K-step's three
-    constexpr int WP = SLAB / 16;                                            // DMA pieces per slice: 768 / 384
-    constexpr int NFULL = WP / 64;                                           // waves 0 .. NFULL-1 carry the second / only piece
+    typedef SpFrag<NP> F;
+    constexpr int NTILE = 32 * NT, PIECE = NTILE * 32, SLAB = NP * PIECE;    // bytes: one 16-bit piece [NTILE][16], a K-step's NP
+    constexpr int WP = SLAB / 16;                                            // DMA pieces per slice: 768 / 384 (NP = 2: 512 / 256)
+    constexpr int W1 = WP >= 512 ? 8 : WP / 64;                              // waves 0 .. W1-1 carry pieces 0 .. 511
+    constexpr int W2 = WP > 512 ? (WP - 512) / 64 : 0;                       // waves 0 .. W2-1 a second one (pieces 512 ..)
     char* const sH = smem;                              // [2][SP_HBYTES]
     char* const sW = smem + 2 * SP_HBYTES;              // [3][SLAB]
     float* const sBias = (float*)(sW + 3 * SLAB);       // [Cout]
     const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
     const int li = lane & 31, lh = lane >> 5;
-    // DMA pieces of a kernel slice per thread: NT = 4: 768 = 512 + 256 (waves 0-3 two, waves 4-7 one);
-    // NT = 2: 384 (waves 0-5 one, waves 6-7 none); NT = 1: 192 (waves 0-2).  A wave's count is static.
-    const int nwq = NT == 4 ? (wv < 4 ? 2 : 1) : (wv < NFULL ? 1 : 0);      // NT = 2: waves 0-5, NT = 1: waves 0-2
+    // DMA pieces of a kernel slice per thread, NP = 3: NT = 4: 768 = 512 + 256 (waves 0-3 two, waves 4-7 one); NT = 2: 384
+    // (waves 0-5 one, waves 6-7 none).  NP = 2: NT = 4: 512 (every wave one); NT = 2: 256 (waves 0-3).  A wave's count is static.
+    const int nwq = (wv < W1 ? 1 : 0) + (wv < W2 ? 1 : 0);
+    const SpScale sc = sp_scales<NP>(a.xmax, a.wmax);
     const dasr_lds_addr_t ldsH = DASR_LDS_ADDR(sH) + 1024 * wv, ldsW = DASR_LDS_ADDR(sW) + 1024 * wv;
 
     const int xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3;
@@ -135,8 +302,8 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     auto w_issue = [&](int cc, int tap, int fn0) {
         const char* src = (const char*)a.ws + (size_t)(((fn0 / NTILE) * 9 + tap) * NC + cc) * SLAB + 16 * tid;
         const dasr_lds_addr_t dst = ldsW + (tap % 3) * SLAB;
-        if (NT == 4 || wv < NFULL) DASR_GLDS16(src, dst);                               // pieces 0 .. 511 (NT = 2: 0 .. 383)
-        if (NT == 4 && wv < 4) DASR_GLDS16(src + 16 * SP_NTHR, dst + 1024 * SP_NWV);    // pieces 512 .. 767
+        if (wv < W1) DASR_GLDS16(src, dst);                                             // pieces 0 .. 511 (or fewer)
+        if (wv < W2) DASR_GLDS16(src + 16 * SP_NTHR, dst + 1024 * SP_NWV);              // pieces 512 .. 767
     };
 
     const int Pl = 2 * wv * SP_HW + li;
@@ -160,7 +327,8 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 bv = *(const float4*)(sBias + n0 + 32 * n + 8 * g + 4 * lh);
+                float4 bv = *(const float4*)(sBias + n0 + 32 * n + 8 * g + 4 * lh);
+                if (NP == 2) bv = make_float4(0.f, 0.f, 0.f, 0.f);         // (scaled sums: the bias joins in the epilogue)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     acc[m][n][4 * g] = bv.x; acc[m][n][4 * g + 1] = bv.y;
@@ -193,7 +361,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
 #ifndef DASR_HIPEMU
                 asm volatile("" : "+v"(Pq));
 #endif
-                bf16x8 A[2][3];
+                typename F::type A[2][NP];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int P = Pq + (m + dy) * SP_HW + dx;
@@ -201,24 +369,16 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
                     const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
                     const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
                     const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    sp_split3(xv, A[m][0], A[m][1], A[m][2]);
+                    F::split(xv, sc.sx, A[m]);
                 }
                 DASR_SETPRIO(1);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const bf16x8 B0 = *(const bf16x8*)(wb + n * 1024);
-                    const bf16x8 B1 = *(const bf16x8*)(wb + PIECE + n * 1024);
-                    const bf16x8 B2 = *(const bf16x8*)(wb + 2 * PIECE + n * 1024);
+                    typename F::type Bw[NP];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        // smallest terms first: x0 w2 + x1 w1 + x2 w0, then x0 w1 + x1 w0, then x0 w0
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2, A[m][0], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A[m][1], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][2], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A[m][0], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][1], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][0], acc[m][n], 0, 0, 0);
-                    }
+                    for (int j = 0; j < NP; ++j) Bw[j] = *(const typename F::type*)(wb + j * PIECE + n * 1024);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][n] = F::mma(Bw, A[m], acc[m][n]);     // smallest terms first
                 }
                 DASR_SETPRIO(0);
             }
@@ -229,73 +389,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
         // accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue
         DASR_RAW_BARRIER();
         char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
-        const int wvalid = a.W - x0;
-        const bool is_relu = a.act == DASR_ACT_RELU;
-        const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
-        const bool has_act = a.act != DASR_ACT_NONE;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int gy = y0 + 2 * wv + m;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 pk = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
-                    *(f32x4*)(scr + li * SP_EPITCH + (8 * g + 4 * lh) * 4) = pk;
-                }
-                DASR_WAVE_SYNC();
-                if (gy < a.H) {
-                    if (a.ps_r == 1) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int v = lane + 64 * u, pix = v >> 2, cg = v & 3;
-                            if (pix >= wvalid) continue;
-                            const float4 lo = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg);
-                            const float4 hi = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg + 16);
-                            float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                            const size_t idx = (((size_t)bb * a.H + gy) * a.W + x0 + pix) * a.Cout + n0 + 32 * n + 8 * cg;
-                            if (a.residual) {
-                                const float4 r0 = *(const float4*)(a.residual + idx), r1 = *(const float4*)(a.residual + idx + 4);
-                                o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w;
-                                o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
-                            }
-                            if (has_act) {
-#pragma unroll
-                                for (int t = 0; t < 8; ++t) o[t] = is_relu ? fmaxf(o[t], 0.f) : fmaxf(o[t], o[t] * slope);
-                            }
-                            float* yp = a.y + idx;
-                            if (a.accumulate) {
-                                const float4 o0 = *(const float4*)yp, o1 = *(const float4*)(yp + 4);
-                                o[0] += o0.x; o[1] += o0.y; o[2] += o0.z; o[3] += o0.w;
-                                o[4] += o1.x; o[5] += o1.y; o[6] += o1.z; o[7] += o1.w;
-                            }
-                            *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
-                            *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                        }
-                    } else {
-                        // PixelShuffle(2): out[b, 2gy+i, 2gx+j, c] = conv[b, gy, gx, 4c + 2i + j]: 8 values of c per (pixel, sub-pixel)
-                        const int Cq = a.Cout / 4;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int v = lane + 64 * u, j = v & 1, pix = (v >> 1) & 31, i = v >> 6;
-                            if (pix >= wvalid) continue;
-                            const float* sp = (const float*)(scr + pix * SP_EPITCH) + 2 * i + j;
-                            float o[8];
-#pragma unroll
-                            for (int t = 0; t < 8; ++t) {
-                                const float q = sp[4 * t];
-                                o[t] = !has_act ? q : (is_relu ? fmaxf(q, 0.f) : fmaxf(q, q * slope));
-                            }
-                            float* yp = a.y + (((size_t)bb * a.H * 2 + 2 * gy + i) * ((size_t)a.W * 2) + 2 * (x0 + pix) + j) * Cq +
-                                        (n0 + 32 * n) / 4;
-                            *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
-                            *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                        }
-                    }
-                }
-                DASR_WAVE_SYNC();
-            }
-        }
+        sp_epilogue<NT, NP>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh);
         if (!has_next) break;
         item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
     }
@@ -307,10 +401,14 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
 // against ~420 us of matrix time on the x8 bench's fourteen launches).  The kernel slices of a chunk are tiny here (9 taps x
 // 3 KB), so ALL NINE are fetched with the halo chunk, double-buffered by chunk: one wait + barrier per CHUNK (108 MFMAs per
 // wave), the nine taps run free of synchronisation and the compiler pipelines reads, splits and MFMAs across them.
+template <int NP>
 __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs a) {
     DASR_DYN_SMEM(smem);
-    constexpr int NT = 1, NTILE = 32, PIECE = NTILE * 32, SLAB = 3 * PIECE;   // 3 KB per (tap, chunk)
-    constexpr int WCH = 9 * SLAB, WPC = WCH / 16;                              // a chunk's nine slices: 27 KB = 1728 DMA pieces
+    typedef SpFrag<NP> F;
+    constexpr int NT = 1, NTILE = 32, PIECE = NTILE * 32, SLAB = NP * PIECE;  // 3 KB (NP = 2: 2 KB) per (tap, chunk)
+    constexpr int WCH = 9 * SLAB, WPC = WCH / 16;                              // a chunk's nine slices: 27 KB = 1728 DMA pieces (18 KB = 1152)
+    constexpr int WPT = SLAB / 16;                                             // pieces per tap: 192 (128)
+    constexpr int WU = (WPC + SP_NTHR - 1) / SP_NTHR, WLAST = (WPC - (WU - 1) * SP_NTHR) / 64;   // trips; waves in the last one
     char* const sH = smem;                              // [2][SP_HBYTES]
     char* const sW = smem + 2 * SP_HBYTES;              // [2][WCH]
     float* const sBias = (float*)(sW + 2 * WCH);        // [Cout]
@@ -330,6 +428,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
 
     for (int i = tid; i < a.Cout; i += SP_NTHR) sBias[i] = a.bias ? a.bias[i] : 0.f;
     __syncthreads();
+    const SpScale sc = sp_scales<NP>(a.xmax, a.wmax);
 
     int x0, y0, n0, bb;
     auto decode = [&](int it, int& ox0, int& oy0, int& on0, int& ob) {
@@ -362,7 +461,8 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
         }
     };
     // everything chunk cc of (the item whose halo state is set up, slice fn0) needs: 5 halo pieces + the nine kernel slices
-    // (pieces p = tid + 512 u < 1728: tap p / 192, 16-byte piece p % 192 of that tap's slice; waves 0-2 carry a fourth)
+    // (pieces p = tid + 512 u < 1728: tap p / 192, 16-byte piece p % 192 of that tap's slice; waves 0-2 carry a fourth;
+    // NP = 2: 1152 = 2 x 512 + 128 pieces, 128 per tap, waves 0-1 carry a third)
     auto chunk_issue = [&](int cc, int fn0, int buf) {
 #pragma unroll
         for (int u = 0; u < SP_NHP; ++u) {
@@ -371,10 +471,10 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
         }
         const char* wsrc = (const char*)a.ws + (size_t)(((fn0 / NTILE) * 9) * NC + cc) * SLAB;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < WU; ++u) {
             const int p = tid + SP_NTHR * u;
-            if (u == 3 && wv >= 3) break;                       // (wave-uniform) 1728 = 3 x 512 + 192
-            const int tap = p / 192, q = p - tap * 192;
+            if (u == WU - 1 && wv >= WLAST) break;              // (wave-uniform) 1728 = 3 x 512 + 192, 1152 = 2 x 512 + 128
+            const int tap = p / WPT, q = p - tap * WPT;
             DASR_GLDS16(wsrc + (size_t)tap * NC * SLAB + 16 * q, ldsW + buf * WCH + 1024 * SP_NWV * u);
         }
     };
@@ -395,7 +495,8 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
         f32x16 acc[2][NT];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 bv = *(const float4*)(sBias + n0 + 8 * g + 4 * lh);
+            float4 bv = *(const float4*)(sBias + n0 + 8 * g + 4 * lh);
+            if (NP == 2) bv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 acc[m][0][4 * g] = bv.x; acc[m][0][4 * g + 1] = bv.y;
@@ -420,7 +521,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
 #ifndef DASR_HIPEMU
                 asm volatile("" : "+v"(Pq));
 #endif
-                bf16x8 A[2][3];
+                typename F::type A[2][NP];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int P = Pq + (m + dy) * SP_HW + dx;
@@ -428,21 +529,14 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
                     const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
                     const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
                     const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    sp_split3(xv, A[m][0], A[m][1], A[m][2]);
+                    F::split(xv, sc.sx, A[m]);
                 }
                 const char* const wb = wc + tap * SLAB;
-                const bf16x8 B0 = *(const bf16x8*)(wb);
-                const bf16x8 B1 = *(const bf16x8*)(wb + PIECE);
-                const bf16x8 B2 = *(const bf16x8*)(wb + 2 * PIECE);
+                typename F::type Bw[NP];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2, A[m][0], acc[m][0], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A[m][1], acc[m][0], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][2], acc[m][0], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A[m][0], acc[m][0], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][1], acc[m][0], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A[m][0], acc[m][0], 0, 0, 0);
-                }
+                for (int j = 0; j < NP; ++j) Bw[j] = *(const typename F::type*)(wb + j * PIECE);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m][0] = F::mma(Bw, A[m], acc[m][0]);
             }
             par ^= 1;
         }
@@ -451,86 +545,24 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
         // accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue
         DASR_RAW_BARRIER();
         char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
-        const int wvalid = a.W - x0;
-        const bool is_relu = a.act == DASR_ACT_RELU;
-        const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
-        const bool has_act = a.act != DASR_ACT_NONE;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int gy = y0 + 2 * wv + m;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 pk = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
-                    *(f32x4*)(scr + li * SP_EPITCH + (8 * g + 4 * lh) * 4) = pk;
-                }
-                DASR_WAVE_SYNC();
-                if (gy < a.H) {
-                    if (a.ps_r == 1) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int v = lane + 64 * u, pix = v >> 2, cg = v & 3;
-                            if (pix >= wvalid) continue;
-                            const float4 lo = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg);
-                            const float4 hi = *(const float4*)(scr + pix * SP_EPITCH + 32 * cg + 16);
-                            float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                            const size_t idx = (((size_t)bb * a.H + gy) * a.W + x0 + pix) * a.Cout + n0 + 32 * n + 8 * cg;
-                            if (a.residual) {
-                                const float4 r0 = *(const float4*)(a.residual + idx), r1 = *(const float4*)(a.residual + idx + 4);
-                                o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w;
-                                o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
-                            }
-                            if (has_act) {
-#pragma unroll
-                                for (int t = 0; t < 8; ++t) o[t] = is_relu ? fmaxf(o[t], 0.f) : fmaxf(o[t], o[t] * slope);
-                            }
-                            float* yp = a.y + idx;
-                            if (a.accumulate) {
-                                const float4 o0 = *(const float4*)yp, o1 = *(const float4*)(yp + 4);
-                                o[0] += o0.x; o[1] += o0.y; o[2] += o0.z; o[3] += o0.w;
-                                o[4] += o1.x; o[5] += o1.y; o[6] += o1.z; o[7] += o1.w;
-                            }
-                            *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
-                            *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                        }
-                    } else {
-                        // PixelShuffle(2): out[b, 2gy+i, 2gx+j, c] = conv[b, gy, gx, 4c + 2i + j]: 8 values of c per (pixel, sub-pixel)
-                        const int Cq = a.Cout / 4;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int v = lane + 64 * u, j = v & 1, pix = (v >> 1) & 31, i = v >> 6;
-                            if (pix >= wvalid) continue;
-                            const float* sp = (const float*)(scr + pix * SP_EPITCH) + 2 * i + j;
-                            float o[8];
-#pragma unroll
-                            for (int t = 0; t < 8; ++t) {
-                                const float q = sp[4 * t];
-                                o[t] = !has_act ? q : (is_relu ? fmaxf(q, 0.f) : fmaxf(q, q * slope));
-                            }
-                            float* yp = a.y + (((size_t)bb * a.H * 2 + 2 * gy + i) * ((size_t)a.W * 2) + 2 * (x0 + pix) + j) * Cq +
-                                        (n0 + 32 * n) / 4;
-                            *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
-                            *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                        }
-                    }
-                }
-                DASR_WAVE_SYNC();
-            }
-        }
+        sp_epilogue<NT, NP>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh);
         if (!has_next) break;
         item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
     }
     sp_wait_vm<0>();
 }
 
-// ---- the kernel split: fp32 packed [2][9][Cin][Cout] (plane 0 = HWIO) -> bf16 image of both modes
+// ---- the kernel split: fp32 packed [2][9][Cin][Cout] (plane 0 = HWIO) -> 16-bit image of both modes
 //   ws[mode][slice][tap][chunk][piece j][row r][16],  element kk of row r at half (kk >> 3) ^ ((r >> 3) & 1)
 //   mode 0 (forward): rows = output channels, K = input channels:  w[tap][16 chunk + kk][slice * NTILE + r]
 //   mode 1 (dgrad):   rows = input channels,  K = output channels: w[8 - tap][slice * NTILE + r][16 chunk + kk]
+// NP = 3: three bf16 pieces; NP = 2: two fp16 pieces of w 2^k, k from *wmax (the max |w| of plane 0, dasr_absmax)
 __host__ __device__ static inline int sp_ntile(int N) { return (N % 128) == 0 ? 128 : ((N % 64) == 0 ? 64 : 32); }
-__global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__ w, bf16_t* __restrict__ ws, int Cin, int Cout) {
-    const size_t per_mode = (size_t)27 * Cin * Cout;
+template <int NP>
+__global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__ w, unsigned short* __restrict__ ws, int Cin, int Cout,
+                                                       const float* __restrict__ wmax) {
+    const size_t per_mode = (size_t)9 * NP * Cin * Cout;
+    const float sw = NP == 2 ? sp_pow2(sp_scale_exp(*wmax)) : 1.f;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < 2 * (size_t)9 * Cin * Cout; idx += (size_t)gridDim.x * 256) {
         const int mode = idx >= (size_t)9 * Cin * Cout;
         size_t e = idx - (size_t)mode * 9 * Cin * Cout;
@@ -544,16 +576,69 @@ __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__
         const int ns = (int)(e / 9);
         const int n = ns * NTILE + r, k = 16 * cc + kk;
         const float v = mode == 0 ? w[((size_t)tap * Cin + k) * Cout + n] : w[((size_t)(8 - tap) * Cin + n) * Cout + k];
-        const bf16_t h0 = dasr_f2bf(v);
-        const float r1 = v - dasr_bf2f(h0);
-        const bf16_t h1 = dasr_f2bf(r1);
-        const bf16_t h2 = dasr_f2bf(r1 - dasr_bf2f(h1));
-        const size_t slab = (((size_t)ns * 9 + tap) * NCk + cc) * 3 * NTILE * 16;
+        const size_t slab = (((size_t)ns * 9 + tap) * NCk + cc) * NP * NTILE * 16;
         const int pos = r * 16 + (((kk >> 3) ^ ((r >> 3) & 1)) << 3) + (kk & 7);
-        bf16_t* o = ws + (size_t)mode * per_mode + slab + pos;
-        o[0] = h0;
-        o[(size_t)NTILE * 16] = h1;
-        o[(size_t)2 * NTILE * 16] = h2;
+        unsigned short* o = ws + (size_t)mode * per_mode + slab + pos;
+        if (NP == 3) {
+            const bf16_t h0 = dasr_f2bf(v);
+            const float r1 = v - dasr_bf2f(h0);
+            const bf16_t h1 = dasr_f2bf(r1);
+            const bf16_t h2 = dasr_f2bf(r1 - dasr_bf2f(h1));
+            memcpy(o, &h0, 2);
+            memcpy(o + (size_t)NTILE * 16, &h1, 2);
+            memcpy(o + (size_t)2 * NTILE * 16, &h2, 2);
+        } else {
+            const float vs = v * sw;
+            const f16_t h0 = (f16_t)vs;
+            const f16_t h1 = (f16_t)(vs - (float)h0);
+            memcpy(o, &h0, 2);
+            memcpy(o + (size_t)NTILE * 16, &h1, 2);
+        }
+    }
+}
+
+// ---- max |x| of a tensor, left in device memory for the fp16 scheme's scale (non-negative floats order like their bits:
+// one atomicMax per workgroup on the word; the entry point clears it first)
+__global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, size_t n4, size_t n, unsigned* __restrict__ out) {
+    __shared__ unsigned sm[4];
+    unsigned m = 0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    // four loads in flight per trip; indices past the end re-read the last piece (harmless for a maximum)
+    if (n4 > 0)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t j = i + u * stride;
+                v[u] = ((const float4*)x)[j < n4 ? j : n4 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned a, b, c, d;
+                memcpy(&a, &v[u].x, 4); memcpy(&b, &v[u].y, 4); memcpy(&c, &v[u].z, 4); memcpy(&d, &v[u].w, 4);
+                a &= 0x7fffffffu; b &= 0x7fffffffu; c &= 0x7fffffffu; d &= 0x7fffffffu;
+                a = a > b ? a : b; c = c > d ? c : d; a = a > c ? a : c;
+                m = m > a ? m : a;
+            }
+        }
+    if (blockIdx.x == 0)
+        for (size_t i = 4 * n4 + threadIdx.x; i < n; i += 256) {
+            unsigned a;
+            memcpy(&a, x + i, 4);
+            a &= 0x7fffffffu;
+            m = m > a ? m : a;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o);
+        m = m > t ? m : t;
+    }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+        a = a > b ? a : b;
+        if (a) atomicMax(out, a);
     }
 }
 
@@ -564,16 +649,42 @@ static bool sp_ok(int H, int W, int K, int N) {
 extern "C" int dasr_conv3x3_split_supported(int H, int W, int Cin, int Cout) {
     return (sp_ok(H, W, Cin, Cout) && sp_ok(H, W, Cout, Cin)) ? 1 : 0;      // forward and dgrad
 }
+extern "C" int dasr_absmax(const float* x, size_t n, float* amax, void* stream) {
+    DASR_CHECK_PTR(x); DASR_CHECK_PTR(amax);
+    DASR_CHECK_SHAPE(n > 0 && (((size_t)x) & 15) == 0);
+    hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    const size_t n4 = n / 4;
+    size_t g = (n4 + 256 * 8 - 1) / (256 * 8);           // ~8 float4 per thread
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    DASR_LAUNCH(k_absmax, dim3((unsigned)g), dim3(256), 0, stream, x, n4, n, (unsigned*)amax);
+    DASR_RETURN_LAUNCH_STATUS();
+}
 extern "C" size_t dasr_conv3x3_split_weights_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0) return 0;
     return sizeof(bf16_t) * (size_t)54 * Cin * Cout;
 }
+extern "C" size_t dasr_conv3x3_split2_weights_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return sizeof(f16_t) * (size_t)36 * Cin * Cout;
+}
 extern "C" int dasr_conv3x3_split_weights(const float* w_packed, unsigned short* w_split, int Cin, int Cout, void* stream) {
     DASR_CHECK_PTR(w_packed); DASR_CHECK_PTR(w_split);
     DASR_CHECK_SHAPE(Cin > 0 && Cout > 0 && (Cin % 32) == 0 && (Cout % 32) == 0);
-    DASR_LAUNCH(k_split_weights, dim3(dasr_ew_grid((size_t)18 * Cin * Cout)), dim3(256), 0, stream, w_packed, (bf16_t*)w_split, Cin, Cout);
+    DASR_LAUNCH((k_split_weights<3>), dim3(dasr_ew_grid((size_t)18 * Cin * Cout)), dim3(256), 0, stream, w_packed, w_split, Cin, Cout,
+                (const float*)nullptr);
     DASR_RETURN_LAUNCH_STATUS();
 }
+extern "C" int dasr_conv3x3_split2_weights(const float* w_packed, const float* wmax, unsigned short* w_split, int Cin, int Cout,
+                                           void* stream) {
+    DASR_CHECK_PTR(w_packed); DASR_CHECK_PTR(w_split); DASR_CHECK_PTR(wmax);
+    DASR_CHECK_SHAPE(Cin > 0 && Cout > 0 && (Cin % 32) == 0 && (Cout % 32) == 0);
+    DASR_LAUNCH((k_split_weights<2>), dim3(dasr_ew_grid((size_t)18 * Cin * Cout)), dim3(256), 0, stream, w_packed, w_split, Cin, Cout,
+                wmax);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+template <int NP>
 static int sp_launch(ConvSplitArgs& a, void* stream) {
     const int NT = sp_ntile(a.Cout) / 32;
     a.tiles_x = (a.W + 31) / 32;
@@ -583,35 +694,55 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
     a.Q = (a.nitems + 7) / 8;
     a.G8 = a.Q < 32 ? a.Q : 32;
     if ((dasr_get_conv_bf16_impl() & 3) == 2) a.G8 = 1;        // tests: one workgroup per XCD walks every item of it
-    const size_t lds = 2 * (size_t)SP_HBYTES + (NT == 1 ? 2 * (size_t)(9 * 3 * 32 * 32) : 3 * (size_t)(3 * 32 * NT * 32)) +
+    const size_t lds = 2 * (size_t)SP_HBYTES + (NT == 1 ? 2 * (size_t)(9 * NP * 32 * 32) : 3 * (size_t)(NP * 32 * NT * 32)) +
                        sizeof(float) * (size_t)a.Cout;
     const dim3 grid(8 * a.G8);
-    if (NT == 4)      DASR_LAUNCH((k_conv3x3_split<4>), grid, dim3(SP_NTHR), lds, stream, a);
-    else if (NT == 2) DASR_LAUNCH((k_conv3x3_split<2>), grid, dim3(SP_NTHR), lds, stream, a);
-    else              DASR_LAUNCH(k_conv3x3_split_n32, grid, dim3(SP_NTHR), lds, stream, a);
+    if (NT == 4)      DASR_LAUNCH((k_conv3x3_split<4, NP>), grid, dim3(SP_NTHR), lds, stream, a);
+    else if (NT == 2) DASR_LAUNCH((k_conv3x3_split<2, NP>), grid, dim3(SP_NTHR), lds, stream, a);
+    else              DASR_LAUNCH((k_conv3x3_split_n32<NP>), grid, dim3(SP_NTHR), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
 }
-extern "C" int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const float* bias,
-                                      const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int act,
-                                      int ps_r, void* stream) {
+static int sp_fwd(const float* x, const float* xmax, const unsigned short* w_split, const float* wmax, const float* bias,
+                  const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int act, int ps_r, void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(w_split); DASR_CHECK_PTR(y);
     DASR_CHECK_SHAPE(B > 0);
     if (!dasr_conv3x3_split_supported(H, W, Cin, Cout)) return DASR_E_UNSUPPORTED;
     if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
     if (ps_r < 1) ps_r = 1;
     if (ps_r > 2 || (ps_r == 2 && (residual != nullptr || (Cout % 128) != 0))) return DASR_E_UNSUPPORTED;
-    ConvSplitArgs a{x, (const bf16_t*)w_split, bias, residual, y, B, H, W, Cin, Cout, 0, act, ps_r, 0, 0, 0, 0, 0, 0};
-    return sp_launch(a, stream);
+    ConvSplitArgs a{x, (const bf16_t*)w_split, bias, residual, y, B, H, W, Cin, Cout, 0, act, ps_r, 0, 0, 0, 0, 0, 0, xmax, wmax};
+    return xmax ? sp_launch<2>(a, stream) : sp_launch<3>(a, stream);
+}
+extern "C" int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const float* bias,
+                                      const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int act,
+                                      int ps_r, void* stream) {
+    return sp_fwd(x, nullptr, w_split, nullptr, bias, residual, y, B, H, W, Cin, Cout, act, ps_r, stream);
+}
+extern "C" int dasr_conv3x3_fwd_split2(const float* x, const float* xmax, const unsigned short* w_split, const float* wmax,
+                                       const float* bias, const float* residual, float* y, int B, int H, int W, int Cin,
+                                       int Cout, int act, int ps_r, void* stream) {
+    DASR_CHECK_PTR(xmax); DASR_CHECK_PTR(wmax);
+    return sp_fwd(x, xmax, w_split, wmax, bias, residual, y, B, H, W, Cin, Cout, act, ps_r, stream);
 }
 // dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * w[tap][ci][co]: mode 1 of the split image (taps already flipped)
-extern "C" int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short* w_split, float* dx, int accumulate, int B,
-                                        int H, int W, int Cin, int Cout, void* stream) {
+static int sp_dgrad(const float* dconv, const float* dmax, const unsigned short* w_split, const float* wmax, float* dx,
+                    int accumulate, int B, int H, int W, int Cin, int Cout, void* stream) {
     DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(w_split); DASR_CHECK_PTR(dx);
     DASR_CHECK_SHAPE(B > 0);
     if (!dasr_conv3x3_split_supported(H, W, Cin, Cout)) return DASR_E_UNSUPPORTED;
-    ConvSplitArgs a{dconv, (const bf16_t*)w_split + (size_t)27 * Cin * Cout, nullptr, nullptr, dx, B, H, W, Cout, Cin,
-                    accumulate, DASR_ACT_NONE, 1, 0, 0, 0, 0, 0, 0};
-    return sp_launch(a, stream);
+    const size_t mode1 = (size_t)9 * (dmax ? 2 : 3) * Cin * Cout;
+    ConvSplitArgs a{dconv, (const bf16_t*)w_split + mode1, nullptr, nullptr, dx, B, H, W, Cout, Cin,
+                    accumulate, DASR_ACT_NONE, 1, 0, 0, 0, 0, 0, 0, dmax, wmax};
+    return dmax ? sp_launch<2>(a, stream) : sp_launch<3>(a, stream);
+}
+extern "C" int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short* w_split, float* dx, int accumulate, int B,
+                                        int H, int W, int Cin, int Cout, void* stream) {
+    return sp_dgrad(dconv, nullptr, w_split, nullptr, dx, accumulate, B, H, W, Cin, Cout, stream);
+}
+extern "C" int dasr_conv3x3_dgrad_split2(const float* dconv, const float* dmax, const unsigned short* w_split, const float* wmax,
+                                         float* dx, int accumulate, int B, int H, int W, int Cin, int Cout, void* stream) {
+    DASR_CHECK_PTR(dmax); DASR_CHECK_PTR(wmax);
+    return sp_dgrad(dconv, dmax, w_split, wmax, dx, accumulate, B, H, W, Cin, Cout, stream);
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
@@ -631,6 +762,8 @@ extern "C" int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short
 __host__ __device__ constexpr int sw_th(int MT, int NTW) { return MT * NTW == 4 ? 2 : (MT * NTW == 2 ? 4 : 8); }
 
 struct SplitWgradArgs {
+    const float* xmax;   // NP = 2: max |x|, max |dy| in device memory (dasr_absmax)
+    const float* dmax;
     const float* x;      // [B,H,W,Cin]
     const float* dy;     // [B,H,W,Cout]
     float* slabs;        // [P][9][Cin][Cout]
@@ -649,9 +782,18 @@ __device__ __forceinline__ void sp_split_pair(float v0, float v1, bf16x2_t& h0, 
     h2 = dasr_f2bf2(r0 - dasr_bf2f(h1[0]), r1 - dasr_bf2f(h1[1]));
 }
 
-template <int MT, int NTW>
+// (NP = 2) two values times the tensor's scale -> their two fp16 pieces
+__device__ __forceinline__ void sp_split_pair2(float v0, float v1, float s, f16x2_t& h0, f16x2_t& h1) {
+    v0 *= s; v1 *= s;
+    h0[0] = (f16_t)v0; h0[1] = (f16_t)v1;
+    h1[0] = (f16_t)(v0 - (float)h0[0]); h1[1] = (f16_t)(v1 - (float)h0[1]);
+}
+
+template <int MT, int NTW, int NP>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a) {
     DASR_DYN_SMEM(smem);
+    typedef SpFrag<NP> F;
+    typedef typename F::elem E;
     constexpr int CIG = 32 * MT, COG = 32 * NTW, TH = sw_th(MT, NTW), HW = SW_TW + 2;
     constexpr int PAIRS = MT * NTW, G = 4 / PAIRS;
     float* sX = (float*)smem;                                   // [(TH+2)*HW][CIG]
@@ -671,6 +813,11 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const bool do_bias = a.bslabs != nullptr && ci0 == 0 && tid < COG;
     float bsum = 0.f;
+    float sx = 1.f, sd = 1.f, inv = 1.f;
+    if (NP == 2) {
+        const int kx = sp_scale_exp(*a.xmax), kd = sp_scale_exp(*a.dmax);
+        sx = sp_pow2(kx); sd = sp_pow2(kd); inv = sp_pow2(-(kx + kd));
+    }
     if (a.zero) {
         const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
         for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
@@ -731,16 +878,23 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
         for (int s = grp; s < TH * 2; s += G) {
             const int py = s >> 1, pc = 16 * (s & 1) + 8 * lh;       // this lane's first pixel column of the K-step
             // dconv operand: 8 pixels of channel co0 + 32 nt + li
-            bf16x8 B0, B1, B2;
+            typename F::type Bd[NP];
             {
                 const float* dp = sD + (py * SW_TW + pc) * COG + 32 * nt + li;
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    bf16x2_t h0, h1, h2;
-                    sp_split_pair(dp[e * COG], dp[(e + 1) * COG], h0, h1, h2);
-                    B0[e] = h0[0]; B0[e + 1] = h0[1];
-                    B1[e] = h1[0]; B1[e + 1] = h1[1];
-                    B2[e] = h2[0]; B2[e + 1] = h2[1];
+                    if constexpr (NP == 3) {
+                        bf16x2_t h0, h1, h2;
+                        sp_split_pair(dp[e * COG], dp[(e + 1) * COG], h0, h1, h2);
+                        Bd[0][e] = h0[0]; Bd[0][e + 1] = h0[1];
+                        Bd[1][e] = h1[0]; Bd[1][e + 1] = h1[1];
+                        Bd[2][e] = h2[0]; Bd[2][e + 1] = h2[1];
+                    } else {
+                        f16x2_t h0, h1;
+                        sp_split_pair2(dp[e * COG], dp[(e + 1) * COG], sd, h0, h1);
+                        Bd[0][e] = h0[0]; Bd[0][e + 1] = h0[1];
+                        Bd[1][e] = h1[0]; Bd[1][e + 1] = h1[1];
+                    }
                 }
             }
 #pragma unroll
@@ -748,28 +902,31 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
                 // x operand: halo columns pc .. pc + 9 of halo row py + dy, channel ci0 + 32 mt + li: the three taps of this
                 // kernel row use columns dx .. dx + 7
                 const float* xp = sX + ((py + dy) * HW + pc) * CIG + 32 * mt + li;
-                bf16_t p0[10], p1[10], p2[10];
+                E pc_[NP][10];
 #pragma unroll
                 for (int e = 0; e < 10; e += 2) {
-                    bf16x2_t h0, h1, h2;
-                    sp_split_pair(xp[e * CIG], xp[(e + 1) * CIG], h0, h1, h2);
-                    p0[e] = h0[0]; p0[e + 1] = h0[1];
-                    p1[e] = h1[0]; p1[e + 1] = h1[1];
-                    p2[e] = h2[0]; p2[e + 1] = h2[1];
+                    if constexpr (NP == 3) {
+                        bf16x2_t h0, h1, h2;
+                        sp_split_pair(xp[e * CIG], xp[(e + 1) * CIG], h0, h1, h2);
+                        pc_[0][e] = h0[0]; pc_[0][e + 1] = h0[1];
+                        pc_[1][e] = h1[0]; pc_[1][e + 1] = h1[1];
+                        pc_[2][e] = h2[0]; pc_[2][e + 1] = h2[1];
+                    } else {
+                        f16x2_t h0, h1;
+                        sp_split_pair2(xp[e * CIG], xp[(e + 1) * CIG], sx, h0, h1);
+                        pc_[0][e] = h0[0]; pc_[0][e + 1] = h0[1];
+                        pc_[1][e] = h1[0]; pc_[1][e + 1] = h1[1];
+                    }
                 }
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    bf16x8 A0, A1, A2;
+                    typename F::type Ax[NP];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { A0[e] = p0[e + dx]; A1[e] = p1[e + dx]; A2[e] = p2[e + dx]; }
-                    f32x16 c = acc[3 * dy + dx];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B0, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B2, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, c, 0, 0, 0);
-                    acc[3 * dy + dx] = c;
+                    for (int j = 0; j < NP; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) Ax[j][e] = pc_[j][e + dx];
+                    // (M = ci: the x fragment is the MFMA's first operand; the product set is symmetric in the two)
+                    acc[3 * dy + dx] = F::mma(Ax, Bd, acc[3 * dy + dx]);
                 }
             }
         }
@@ -804,7 +961,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = acc[tap][r];
+            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = NP == 2 ? acc[tap][r] * inv : acc[tap][r];
         }
     }
 }
@@ -826,8 +983,9 @@ extern "C" size_t dasr_conv3x3_wgrad_split_workspace(int B, int H, int W, int Ci
     sw_plan(B, H, W, Cin, Cout, MT, NTW, groups, ntiles, P);
     return sizeof(float) * ((size_t)P * 9 * Cin * Cout + (size_t)P * Cout);
 }
-extern "C" int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
-                                        size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream) {
+template <int NP>
+static int sw_launch(const float* x, const float* xmax, const float* dconv, const float* dmax, float* dw, float* dbias,
+                     void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(dconv); DASR_CHECK_PTR(dw); DASR_CHECK_PTR(workspace);
     DASR_CHECK_SHAPE(B > 0 && H > 0 && W > 0);
     if ((Cin % 32) != 0 || (Cout % 32) != 0) return DASR_E_UNSUPPORTED;
@@ -841,14 +999,24 @@ extern "C" int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, floa
     unsigned gx = dasr_cdiv(nW / 4, 256);
     int ysplit = 1;
     while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
-    SplitWgradArgs a{x, dconv, slabs, bslabs, ysplit > 1 ? dw : nullptr, ysplit > 1 ? nW : 0, B, H, W, Cin, Cout, P, ntiles};
+    SplitWgradArgs a{xmax, dmax, x, dconv, slabs, bslabs, ysplit > 1 ? dw : nullptr, ysplit > 1 ? nW : 0, B, H, W, Cin, Cout, P, ntiles};
     const int th = sw_th(MT, NTW);
     const size_t lds = sizeof(float) * (size_t)((th + 2) * (SW_TW + 2) * 32 * MT + th * SW_TW * 32 * NTW);
     const dim3 grid(groups, P);
-    if (MT == 2 && NTW == 2)      DASR_LAUNCH((k_conv3x3_wgrad_split<2, 2>), grid, dim3(256), lds, stream, a);
-    else if (MT == 1 && NTW == 4) DASR_LAUNCH((k_conv3x3_wgrad_split<1, 4>), grid, dim3(256), lds, stream, a);
-    else if (MT == 2 && NTW == 1) DASR_LAUNCH((k_conv3x3_wgrad_split<2, 1>), grid, dim3(256), lds, stream, a);
-    else if (MT == 1 && NTW == 2) DASR_LAUNCH((k_conv3x3_wgrad_split<1, 2>), grid, dim3(256), lds, stream, a);
-    else                          DASR_LAUNCH((k_conv3x3_wgrad_split<1, 1>), grid, dim3(256), lds, stream, a);
+    if (MT == 2 && NTW == 2)      DASR_LAUNCH((k_conv3x3_wgrad_split<2, 2, NP>), grid, dim3(256), lds, stream, a);
+    else if (MT == 1 && NTW == 4) DASR_LAUNCH((k_conv3x3_wgrad_split<1, 4, NP>), grid, dim3(256), lds, stream, a);
+    else if (MT == 2 && NTW == 1) DASR_LAUNCH((k_conv3x3_wgrad_split<2, 1, NP>), grid, dim3(256), lds, stream, a);
+    else if (MT == 1 && NTW == 2) DASR_LAUNCH((k_conv3x3_wgrad_split<1, 2, NP>), grid, dim3(256), lds, stream, a);
+    else                          DASR_LAUNCH((k_conv3x3_wgrad_split<1, 1, NP>), grid, dim3(256), lds, stream, a);
     return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit > 1, bslabs, dbias, Cout);
+}
+extern "C" int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
+                                        size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream) {
+    return sw_launch<3>(x, nullptr, dconv, nullptr, dw, dbias, workspace, workspace_bytes, B, H, W, Cin, Cout, stream);
+}
+extern "C" int dasr_conv3x3_wgrad_split2(const float* x, const float* xmax, const float* dconv, const float* dmax, float* dw,
+                                         float* dbias, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin,
+                                         int Cout, void* stream) {
+    DASR_CHECK_PTR(xmax); DASR_CHECK_PTR(dmax);
+    return sw_launch<2>(x, xmax, dconv, dmax, dw, dbias, workspace, workspace_bytes, B, H, W, Cin, Cout, stream);
 }

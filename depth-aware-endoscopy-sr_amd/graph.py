@@ -37,6 +37,9 @@ ENCODER_S2D = True     # bf16 path: encoder layers 2-5 on the bf16 stride-1 kern
 # Weight gradients stay on the exact-fp32 MFMA kernels.
 SPLIT_BF16 = True
 SPLIT_WGRAD = True              # ... and their weight gradients (K = pixels: operands split at read time)
+# 3: three bf16 pieces, six products.  2: two fp16 pieces, three products, every tensor operand scaled by a power of two taken
+# from its max |.| (ops.absmax, device side): half the matrix work and measurably closer to float64 (csrc/conv_split_bf16.hip).
+SPLIT_PIECES = 2
 SPLIT_MIN_PIXELS = 1 << 14      # below this the launch is latency-bound either way
 WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
@@ -153,6 +156,15 @@ def bias_pair(tape, ba, bb):
     return out
 
 
+def _amax(var):
+    """max |var.data| on the device (ops.absmax), computed once per tensor and stream: the forward convolution and its weight
+    gradient share it."""
+    key = torch.cuda.current_stream().cuda_stream if var.data.is_cuda else 0
+    if var.amax is None or var.amax[0] != key:
+        var.amax = (key, ops.absmax(var.data))
+    return var.amax[1]
+
+
 def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.ACT_NONE, ps_r=1, residual=None,
          side_wgrad=False, want_stats=False, out_dtype=None):
     stats = None
@@ -168,9 +180,15 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
           and x.data.shape[0] * x.data.shape[1] * x.data.shape[2] >= SPLIT_MIN_PIXELS
           and ops.conv3x3_split_supported(x.data.shape[1], x.data.shape[2], w.data.shape[3], w.data.shape[4])):
         if w.split is None:           # (eval + no_grad: cached with the folded kernel it is derived from)
-            w.split = _folded(tape, ("split", "@%x" % w.data.data_ptr()), [w.data], lambda: ops.conv3x3_split_weights(w.data))
-        y = ops.conv3x3_fwd_split(x.data, w.split, bias.data if bias is not None else None, w.data.shape[4],
-                                  residual.data if residual is not None else None, act, ps_r)
+            w.split = _folded(tape, ("split%d" % SPLIT_PIECES, "@%x" % w.data.data_ptr()), [w.data],
+                              (lambda: ops.conv3x3_split2_weights(w.data)) if SPLIT_PIECES == 2 else
+                              (lambda: ops.conv3x3_split_weights(w.data)))
+        if isinstance(w.split, tuple):
+            y = ops.conv3x3_fwd_split2(x.data, _amax(x), w.split, bias.data if bias is not None else None, w.data.shape[4],
+                                       residual.data if residual is not None else None, act, ps_r)
+        else:
+            y = ops.conv3x3_fwd_split(x.data, w.split, bias.data if bias is not None else None, w.data.shape[4],
+                                      residual.data if residual is not None else None, act, ps_r)
     else:
         y = ops.conv2d_fwd(x.data, w.data, bias.data if bias is not None else None,
                            residual.data if residual is not None else None, stride, pad, transposed, act, ps_r, out_dtype)
@@ -210,12 +228,17 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             dconv = ops.conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r)
         else:
             dconv = dy
+        dmax = None                          # (fp16 x 2 scheme) max |dconv|, shared by the weight and the data gradient
         if w.requires_grad or (bias is not None and bias.requires_grad):
             ws = _side_stream(dconv.device, "wgrad") if (WGRAD_STREAM and dconv.is_cuda) else None
             if ws is None and side_wgrad and TAIL_WGRAD_SIDE and SIDE_STREAM and dconv.is_cuda:
                 ws = _side_stream(dconv.device)       # the depth-branch stream: idle while the HR tail runs backward
             if ws is None and w.split is not None and SPLIT_WGRAD:
-                dw, db = ops.conv3x3_wgrad_split(x.data, dconv, want_bias=bias is not None)
+                if isinstance(w.split, tuple):
+                    dmax = ops.absmax(dconv)
+                    dw, db = ops.conv3x3_wgrad_split2(x.data, _amax(x), dconv, dmax, want_bias=bias is not None)
+                else:
+                    dw, db = ops.conv3x3_wgrad_split(x.data, dconv, want_bias=bias is not None)
             elif ws is None:
                 dw, db = ops.conv2d_wgrad(x.data, dconv, wshape, stride, pad, transposed, want_bias=bias is not None)
             else:
@@ -243,6 +266,10 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
                 x.grad = ops.conv2d_dgrad_act(dconv, w.data, x.data, x.epilogue[0], x.epilogue[1], stride, pad,
                                               transposed)
                 x.grad_is_preact = True
+            elif isinstance(w.split, tuple):
+                if dmax is None:
+                    dmax = ops.absmax(dconv)
+                x.grad = ops.conv3x3_dgrad_split2(dconv, dmax, w.split, x.data.shape, out=x.grad)
             elif w.split is not None:
                 if x.grad is None:
                     x.grad = ops.conv3x3_dgrad_split(dconv, w.split, x.data.shape)

@@ -431,6 +431,59 @@ def conv3x3_dgrad_split(dconv, ws, x_shape, out=None):
     return out
 
 
+# ---- the same with two fp16 pieces / three products; every tensor operand comes with its max |.| in device memory ----
+def absmax(x):
+    """max |x| as a 1-element device tensor (the fp16 scheme's kernels derive their power-of-two scale from it)."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _call("dasr_absmax", _p(x), x.numel(), _p(out))
+    return out
+
+
+def conv3x3_split2_weights(w):
+    """fp32 packed kernel (2,3,3,Cin,Cout) -> (fp16 two-piece image, max |w| device scalar)."""
+    KH, KW, Cin, Cout = _wdims(w)
+    assert (KH, KW) == (3, 3) and w.dtype == torch.float32
+    wmax = absmax(w[0])
+    n = int(_lib.get().dasr_conv3x3_split2_weights_bytes(Cin, Cout)) // 2
+    ws = torch.empty((n,), dtype=torch.float16, device=w.device)
+    _call("dasr_conv3x3_split2_weights", _p(w), _p(wmax), _lib.ptr(ws, False, torch.float16), Cin, Cout)
+    return ws, wmax
+
+
+def conv3x3_fwd_split2(x, xmax, ws, bias, Cout, residual=None, act=ACT_NONE, ps_r=1):
+    B, H, W, Cin = x.shape
+    if ps_r > 1:
+        y = empty((B, H * ps_r, W * ps_r, Cout // (ps_r * ps_r)), x)
+    else:
+        y = empty((B, H, W, Cout), x)
+    _call("dasr_conv3x3_fwd_split2", _p(x), _p(xmax), _lib.ptr(ws[0], False, torch.float16), _p(ws[1]), _p(bias, True), _p(residual, True), _p(y), B, H, W,
+          Cin, Cout, act, ps_r)
+    return y
+
+
+def conv3x3_wgrad_split2(x, xmax, dconv, dmax, want_bias=True):
+    B, H, W, Cin = x.shape
+    Cout = dconv.shape[3]
+    nbytes = int(_lib.get().dasr_conv3x3_wgrad_split_workspace(B, H, W, Cin, Cout))
+    ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
+    dw = empty((3, 3, Cin, Cout), x)
+    db = empty((Cout,), x) if want_bias else None
+    _call("dasr_conv3x3_wgrad_split2", _p(x), _p(xmax), _p(dconv), _p(dmax), _p(dw), _p(db, True), _p(ws), nbytes, B, H, W, Cin,
+          Cout)
+    return dw, db
+
+
+def conv3x3_dgrad_split2(dconv, dmax, ws, x_shape, out=None):
+    B, H, W, Cin = x_shape
+    Cout = dconv.shape[3]
+    acc = out is not None
+    if out is None:
+        out = empty(tuple(x_shape), dconv)
+    _call("dasr_conv3x3_dgrad_split2", _p(dconv), _p(dmax), _lib.ptr(ws[0], False, torch.float16), _p(ws[1]), _p(out), 1 if acc else 0, B, H, W, Cin, Cout)
+    return out
+
+
 def conv2d_fwd_stats(x, w, bias):
     """3x3 / stride 1 / pad 1 conv (+bias) and the InstanceNorm statistics of its output: (y, mean[B,C], var[B,C])."""
     B, H, W, Cin = x.shape

@@ -12,7 +12,7 @@ from . import ops
 class Var:
     """A device tensor plus its gradient slot."""
     __slots__ = ("data", "grad", "requires_grad", "name", "uses", "epilogue", "grad_is_preact", "event",
-                 "grad_event", "stats", "split")
+                 "grad_event", "stats", "split", "amax")
 
     def __init__(self, data, requires_grad=False, name=None):
         self.data = data
@@ -25,7 +25,8 @@ class Var:
         self.event = None            # HIP event after the producing kernel when it ran on another stream
         self.grad_event = None       # HIP event after the kernel that produced .grad on another stream
         self.stats = None            # (mean, var) per (b, c) when the producing conv computed them in its epilogue
-        self.split = None            # packed fp32 kernels: their bf16 three-piece image (graph.SPLIT_BF16), built at first use
+        self.split = None            # packed fp32 kernels: their bf16 three-piece / fp16 two-piece image (graph.SPLIT_BF16), built at first use
+        self.amax = None             # (stream, max |data| device scalar) for the fp16 x 2 split scheme (graph._amax)
 
     @property
     def shape(self):

@@ -165,6 +165,29 @@ size_t dasr_conv3x3_wgrad_split_workspace(int B, int H, int W, int Cin, int Cout
 int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, float* dw_hwio, float* dbias, void* workspace,
                              size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
 
+/* The same convolutions with TWO fp16 pieces per operand and THREE products per term ("split fp16 x 2", same source file):
+ * fp16 holds 11 significant bits, a pair 22-23 of fp32's 24 (0.5 ulp RMS off - one more fp32 rounding per operand), the
+ * dropped term is 2^-24 relative, and only half as many partial sums are rounded into the fp32 accumulator: measured
+ * against float64 the result is closer than both the bf16 x 3 scheme and the exact-fp32 MFMA kernels.  fp16's narrow range
+ * is handled by a power-of-two scale per tensor that puts its largest magnitude in [2^14, 2^15):
+ *   dasr_absmax:     *amax = max |x| over n floats (x 16-byte aligned); cleared and written on the stream (device memory:
+ *                    the kernels below derive the scale from its exponent bits, nothing is read back by the host)
+ *   split2_weights:  wmax = dasr_absmax of the packed kernel's plane 0 (9 Cin Cout floats); image: split2_weights_bytes
+ *   fwd / dgrad / wgrad_split2: as the functions above plus the maxima of their tensor operands (xmax of x, dmax of dconv)
+ * Same nn.Conv2d calls replaced (normalization.py:41-42,73-74; sftmd_arch.py:811-820 and the upscale tail :891-909). */
+int dasr_absmax(const float* x, size_t n, float* amax, void* stream);
+size_t dasr_conv3x3_split2_weights_bytes(int Cin, int Cout);
+int dasr_conv3x3_split2_weights(const float* w_packed, const float* wmax, unsigned short* w_split, int Cin, int Cout,
+                                void* stream);
+int dasr_conv3x3_fwd_split2(const float* x, const float* xmax, const unsigned short* w_split, const float* wmax,
+                            const float* bias, const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
+                            int act, int ps_r, void* stream);
+int dasr_conv3x3_dgrad_split2(const float* dconv, const float* dmax, const unsigned short* w_split, const float* wmax,
+                              float* dx, int accumulate, int B, int H, int W, int Cin, int Cout, void* stream);
+int dasr_conv3x3_wgrad_split2(const float* x, const float* xmax, const float* dconv, const float* dmax, float* dw_hwio,
+                              float* dbias, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
+                              void* stream);
+
 /* ---- instance-norm statistics ---------------------------------------------------------------
  * nn.InstanceNorm2d(affine=False) appears twice in a row on every DGB conv output
  * (sftmd_arch.py:811-820 then normalization.py:16-17,56).  Both collapse to one per-(b,c) scale:

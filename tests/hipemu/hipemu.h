@@ -110,6 +110,7 @@ static inline int __any(int pred) { return !__all(!pred); }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 
 // ---- MFMA (f32 in / f32 accumulate), fragment layouts per cdna_hip_programming.md §3 -------------
 static inline f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) {
@@ -181,6 +182,30 @@ static inline f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
+// v_mfma_f32_32x32x16_f16: the same operand and result maps with fp16 elements (products exact in fp32)
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+static inline f32x16 hipemu_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, f32x16 c, int, int, int) {
+    char* buf = (char*)hipemu::wave_buf();
+    int l = hipemu::lane_id();
+    memcpy(buf + 64 * l, &a, 16);
+    memcpy(buf + 64 * l + 16, &b, 16);
+    hipemu::wave_barrier();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            _Float16 av, bv;
+            memcpy(&av, buf + 64 * (row + 32 * (k >> 3)) + 2 * (k & 7), 2);
+            memcpy(&bv, buf + 64 * (col + 32 * (k >> 3)) + 16 + 2 * (k & 7), 2);
+            acc = fmaf((float)av, (float)bv, acc);
+        }
+        c[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_f32_32x32x16_f16
 // v_mfma_f32_16x16x32_bf16: A lane l holds A[row l&15][k = 8(l>>4) + j], B lane holds B[k = 8(l>>4) + j][col l&15];
 // C/D: col = lane&15, row = 4*(lane>>4) + reg
 static inline f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, f32x4 c, int, int, int) {

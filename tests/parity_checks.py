@@ -1101,7 +1101,45 @@ def check_region_shortcut_invalidation(device):
     return dict(ok=True)
 
 
-def check_split_conv(device, seed=5):
+class _SplitApi:
+    """The two split schemes behind one face: pieces = 3 (bf16 x 3, six products) / 2 (fp16 x 2, three products, every
+    tensor operand with its dasr_absmax)."""
+
+    def __init__(self, pieces):
+        self.pieces = pieces
+
+    def weights(self, wp):
+        return ops.conv3x3_split_weights(wp) if self.pieces == 3 else ops.conv3x3_split2_weights(wp)
+
+    def fwd(self, x, ws, bias, cout, residual=None, act=0, ps=1):
+        if self.pieces == 3:
+            return ops.conv3x3_fwd_split(x, ws, bias, cout, residual, act, ps)
+        return ops.conv3x3_fwd_split2(x, ops.absmax(x), ws, bias, cout, residual, act, ps)
+
+    def dgrad(self, dy, ws, x_shape, out=None):
+        if self.pieces == 3:
+            return ops.conv3x3_dgrad_split(dy, ws, x_shape, out=out)
+        return ops.conv3x3_dgrad_split2(dy, ops.absmax(dy), ws, x_shape, out=out)
+
+    def wgrad(self, x, dy):
+        if self.pieces == 3:
+            return ops.conv3x3_wgrad_split(x, dy)
+        return ops.conv3x3_wgrad_split2(x, ops.absmax(x), dy, ops.absmax(dy))
+
+
+def check_absmax(device, seed=3):
+    """dasr_absmax against torch, incl. lengths that are not a multiple of four, negative extremes, zeros."""
+    gen = torch.Generator().manual_seed(seed)
+    for n in (4, 7, 1024, 4099, 300001):
+        x = torch.randn(n + 4, generator=gen)[:n].clone()
+        x[n // 2] = -77.5 if n % 2 else 91.25
+        got = ops.absmax(x.to(device)).cpu().item()
+        assert got == x.abs().max().item(), (n, got)
+    assert ops.absmax(torch.zeros(64).to(device)).cpu().item() == 0.0
+    return dict(ok=True)
+
+
+def check_split_conv(device, seed=5, pieces=3):
     """dasr_conv3x3_{fwd,dgrad}_split - fp32 convolutions as six bf16 MFMA products of three-piece operands - against
     torch's FLOAT64 convolution of the same fp32 operands, next to the exact-fp32 MFMA kernels they replace
     (dasr_conv2d_fwd / dasr_conv2d_dgrad): the split kernels must be as close to the float64 result as the fp32 kernels are.
@@ -1110,11 +1148,16 @@ def check_split_conv(device, seed=5):
     CPU emulator models every MFMA as an fp32 fma chain, six times as many roundings as the hardware's: 1.9 .. 2.4x there,
     gate 3x + 2e-7.  Ragged tiles, one to
     four channel slices' worth of rows, 64 / 128 / 256 channels, accumulating dgrad, and - second pass - one workgroup per
-    XCD walking a list of items."""
+    XCD walking a list of items.
+    pieces = 2: the fp16 x 2 scheme (three products, per-tensor power-of-two scales from dasr_absmax) under the SAME gates;
+    its operands are additionally scaled far from 1 (x by 2^9 x 1.3, dy by 3e-8: a gradient-sized tensor) - the error
+    measures are relative, so only the scale handling can tell."""
     gen = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=gen)
     out = {}
     fac, slack = (3.0, 2e-7) if device == "cpu" else (1.25, 1e-7)
+    api = _SplitApi(pieces)
+    sx_, sd_ = (665.6, 3e-8) if pieces == 2 else (1.0, 1.0)
     for mode in (0, 2):
         one_wg = mode
         ops.set_conv_bf16_impl(mode)
@@ -1123,25 +1166,25 @@ def check_split_conv(device, seed=5):
             shapes = {0: [(64, 64, 1, 17, 35), (128, 128, 1, 9, 20)], 2: [(64, 128, 2, 17, 33)]}[mode]
         try:
             for (cin, cout, B, H, W) in shapes:
-                x = rn(B, cin, H, W) * (1.0 + rn(B, cin, 1, 1).abs())
+                x = rn(B, cin, H, W) * (1.0 + rn(B, cin, 1, 1).abs()) * sx_
                 w = rn(cout, cin, 3, 3) * (1.0 / math.sqrt(9 * cin))
-                bias = rn(cout) * 0.3
+                bias = rn(cout) * 0.3 * sx_
                 x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double()
                 ref = F.conv2d(x64, w64, b64, padding=1)
-                dy = rn(B, cout, H, W)
+                dy = rn(B, cout, H, W) * sd_
                 gx64, = torch.autograd.grad(ref, x64, dy.double())
                 assert ops.conv3x3_split_supported(H, W, cin, cout)
                 xd = nhwc(x).to(device)
                 wp = ops.pack_hwio(w.permute(2, 3, 1, 0).contiguous().to(device))
-                ws = ops.conv3x3_split_weights(wp)
+                ws = api.weights(wp)
                 bd = bias.to(device)
-                y_sp = ops.conv3x3_fwd_split(xd, ws, bd, cout)
+                y_sp = api.fwd(xd, ws, bd, cout)
                 y_32 = ops.conv2d_fwd(xd, wp, bd)
                 e_sp = (nchw(y_sp.cpu()).double() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
                 e_32 = (nchw(y_32.cpu()).double() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
                 assert e_sp <= fac * e_32 + slack, ("fwd", cin, cout, H, W, e_sp, e_32)
                 dyd = nhwc(dy).to(device)
-                dx_sp = ops.conv3x3_dgrad_split(dyd, ws, xd.shape)
+                dx_sp = api.dgrad(dyd, ws, xd.shape)
                 dx_32 = ops.conv2d_dgrad(dyd, wp, xd.shape)
                 g_sp = (nchw(dx_sp.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
                 g_32 = (nchw(dx_32.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
@@ -1149,14 +1192,14 @@ def check_split_conv(device, seed=5):
                 # weight / bias gradient
                 gw64, = torch.autograd.grad(F.conv2d(x64, w64, b64, padding=1), w64, dy.double())
                 gb64 = dy.double().sum((0, 2, 3))
-                dw_sp, db_sp = ops.conv3x3_wgrad_split(xd, dyd)
+                dw_sp, db_sp = api.wgrad(xd, dyd)
                 dw_32, db_32 = ops.conv2d_wgrad(xd, dyd, (3, 3, cin, cout))
                 w_sp, w_32 = rel_max(dw_sp.permute(3, 2, 0, 1), gw64), rel_max(dw_32.permute(3, 2, 0, 1), gw64)
                 assert w_sp <= fac * w_32 + slack, ("wgrad", cin, cout, H, W, w_sp, w_32)
                 assert rel_max(db_sp, gb64) <= 2 * rel_max(db_32, gb64) + 1e-6, ("dbias", cin, cout)
-                base = rn(B, H, W, cin)
+                base = rn(B, H, W, cin) * sd_
                 accd = base.to(device).clone()
-                ops.conv3x3_dgrad_split(dyd, ws, xd.shape, out=accd)
+                api.dgrad(dyd, ws, xd.shape, out=accd)
                 want = nhwc(gx64) + base.double()
                 g_acc = (accd.cpu().double() - want).abs().max().item() / want.abs().max().item()
                 assert g_acc <= fac * g_32 + 2 * slack, ("dgrad accumulate", cin, cout, g_acc)
@@ -1180,9 +1223,9 @@ def check_split_conv(device, seed=5):
                 ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.2) if act == 2 else ref)
                 xd = nhwc(x).to(device)
                 wp = ops.pack_hwio(w.permute(2, 3, 1, 0).contiguous().to(device))
-                ws = ops.conv3x3_split_weights(wp)
+                ws = api.weights(wp)
                 rd = nhwc(r).to(device) if res else None
-                y_sp = ops.conv3x3_fwd_split(xd, ws, bias.to(device), cout, rd, act, ps)
+                y_sp = api.fwd(xd, ws, bias.to(device), cout, rd, act, ps)
                 y_32 = ops.conv2d_fwd(xd, wp, bias.to(device), rd, 1, 1, False, act, ps)
                 assert tuple(y_sp.shape) == tuple(y_32.shape) == tuple(nhwc(ref).shape)
                 e_sp = (nchw(y_sp.cpu()).double() - ref).abs().max().item() / ref.abs().max().item()
@@ -1193,13 +1236,13 @@ def check_split_conv(device, seed=5):
                                             [], dy.double(), allow_unused=True) if False else (None,)
                 x64 = x.double().requires_grad_(True)
                 gx64, = torch.autograd.grad(F.conv2d(x64, w.double(), None, padding=1), x64, dy.double())
-                dx_sp = ops.conv3x3_dgrad_split(nhwc(dy).to(device), ws, xd.shape)
+                dx_sp = api.dgrad(nhwc(dy).to(device), ws, xd.shape)
                 g_sp = (nchw(dx_sp.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
                 assert g_sp <= 4e-6, ("dgrad 32-channel", cin, cout, g_sp)
                 # weight gradient of the smaller (ci, co) blocks: 32 x 32, 64 x 32, 32 x 128 (waves split the K-steps)
                 w64 = w.double().requires_grad_(True)
                 gw64, = torch.autograd.grad(F.conv2d(x.double(), w64, None, padding=1), w64, dy.double())
-                dw_sp, db_sp = ops.conv3x3_wgrad_split(xd, nhwc(dy).to(device))
+                dw_sp, db_sp = api.wgrad(xd, nhwc(dy).to(device))
                 dw_32, _ = ops.conv2d_wgrad(xd, nhwc(dy).to(device), (3, 3, cin, cout))
                 w_sp, w_32 = rel_max(dw_sp.permute(3, 2, 0, 1), gw64), rel_max(dw_32.permute(3, 2, 0, 1), gw64)
                 assert w_sp <= fac * w_32 + slack, ("wgrad small block", cin, cout, w_sp, w_32)

@@ -28,8 +28,13 @@ def test_pixel_shuffle_bit_exact():
     pc.check_pixel_shuffle_bit_exact("cuda")
 
 
-def test_split_conv():
-    print(pc.check_split_conv("cuda"))
+@pytest.mark.parametrize("pieces", [3, 2], ids=["bf16x3", "fp16x2"])
+def test_split_conv(pieces):
+    print(pc.check_split_conv("cuda", pieces=pieces))
+
+
+def test_absmax():
+    print(pc.check_absmax("cuda"))
 
 
 def test_ssim_kernel():
@@ -85,17 +90,19 @@ _SPLIT_CASES = [pytest.param(c, id=c["name"], marks=pytest.mark.xfail(reason="Re
                 for c in DEPTHNET_CASES]
 
 
+@pytest.mark.parametrize("pieces", [3, 2], ids=["bf16x3", "fp16x2"])
 @pytest.mark.parametrize("case", _SPLIT_CASES)
-def test_depthnet_split_bf16(case):
-    """The whole-net golden cases with the split-bf16 convolutions FORCED on (by default they take over above
-    graph.SPLIT_MIN_PIXELS pixels only, i.e. never at these tiny frames): the fp32 gates, unchanged."""
+def test_depthnet_split_bf16(case, pieces):
+    """The whole-net golden cases with the split convolutions FORCED on (by default they take over above
+    graph.SPLIT_MIN_PIXELS pixels only, i.e. never at these tiny frames), in both schemes (three bf16 pieces / two scaled fp16
+    pieces): the fp32 gates, unchanged."""
     from dasr_amd import graph
-    old = graph.SPLIT_MIN_PIXELS
-    graph.SPLIT_MIN_PIXELS = 0
+    old = graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES
+    graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES = 0, pieces
     try:
-        print(case["name"], "split", pc.check_depthnet_case(case, "cuda"))
+        print(case["name"], "split", pieces, pc.check_depthnet_case(case, "cuda"))
     finally:
-        graph.SPLIT_MIN_PIXELS = old
+        graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES = old
 
 
 def test_sean():

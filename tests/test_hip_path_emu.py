@@ -13,8 +13,13 @@ def test_conv_variants(emu):
     pc.check_conv_variants("cpu")
 
 
-def test_split_conv(emu):
-    print(pc.check_split_conv("cpu"))
+@pytest.mark.parametrize("pieces", [3, 2], ids=["bf16x3", "fp16x2"])
+def test_split_conv(emu, pieces):
+    print(pc.check_split_conv("cpu", pieces=pieces))
+
+
+def test_absmax(emu):
+    print(pc.check_absmax("cpu"))
 
 
 def test_pixel_shuffle_bit_exact(emu):

@@ -26,27 +26,45 @@ def timeit(fn, iters=5):
 def main():
     dev = torch.device("cuda")
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    H, W = 128, 160
-    for ci, co in ((128, 128), (64, 64)):
+    H0, W0 = 128, 160
+    shapes = ((128, 128, 1), (64, 64, 1), (64, 256, 1), (64, 32, 2), (32, 128, 2), (32, 32, 4), (32, 128, 4))
+    for ci, co, up in shapes:
+        H, W = H0 * up, W0 * up
         x = torch.randn(B, H, W, ci, device=dev)
         wp = ops.pack_hwio(torch.randn(3, 3, ci, co, device=dev) * 0.05)
         bias = torch.randn(co, device=dev)
         ws = ops.conv3x3_split_weights(wp)
+        ws2 = ops.conv3x3_split2_weights(wp)
         y = ops.conv2d_fwd(x, wp, bias)
+        xm, ym = ops.absmax(x), ops.absmax(y)
         fl = 2.0 * 9 * ci * co * B * H * W
-        r = {k: [] for k in ("f32 fwd", "split fwd", "f32 dgrad", "split dgrad", "f32 wgrad", "split wgrad", "split weights")}
+        keys = ("f32 fwd", "bf16x3 fwd", "fp16x2 fwd", "f32 dgrad", "bf16x3 dgrad", "fp16x2 dgrad", "f32 wgrad", "bf16x3 wgrad",
+                "fp16x2 wgrad", "bf16x3 weights", "fp16x2 weights", "absmax x", "absmax y")
+        r = {k: [] for k in keys}
         for _ in range(3):
             r["f32 fwd"].append(timeit(lambda: ops.conv2d_fwd(x, wp, bias)))
-            r["split fwd"].append(timeit(lambda: ops.conv3x3_fwd_split(x, ws, bias, co)))
+            r["bf16x3 fwd"].append(timeit(lambda: ops.conv3x3_fwd_split(x, ws, bias, co)))
+            r["fp16x2 fwd"].append(timeit(lambda: ops.conv3x3_fwd_split2(x, xm, ws2, bias, co)))
             r["f32 dgrad"].append(timeit(lambda: ops.conv2d_dgrad(y, wp, x.shape)))
-            r["split dgrad"].append(timeit(lambda: ops.conv3x3_dgrad_split(y, ws, x.shape)))
+            r["bf16x3 dgrad"].append(timeit(lambda: ops.conv3x3_dgrad_split(y, ws, x.shape)))
+            r["fp16x2 dgrad"].append(timeit(lambda: ops.conv3x3_dgrad_split2(y, ym, ws2, x.shape)))
             r["f32 wgrad"].append(timeit(lambda: ops.conv2d_wgrad(x, y, (3, 3, ci, co))))
-            r["split wgrad"].append(timeit(lambda: ops.conv3x3_wgrad_split(x, y)))
-            r["split weights"].append(timeit(lambda: ops.conv3x3_split_weights(wp)))
+            r["bf16x3 wgrad"].append(timeit(lambda: ops.conv3x3_wgrad_split(x, y)))
+            r["fp16x2 wgrad"].append(timeit(lambda: ops.conv3x3_wgrad_split2(x, xm, y, ym)))
+            r["bf16x3 weights"].append(timeit(lambda: ops.conv3x3_split_weights(wp)))
+            r["fp16x2 weights"].append(timeit(lambda: ops.conv3x3_split2_weights(wp)))
+            r["absmax x"].append(timeit(lambda: ops.absmax(x)))
+            r["absmax y"].append(timeit(lambda: ops.absmax(y)))
         for k, v in r.items():
             us = sorted(v)[1]
-            print("B=%d %3d->%3d %-14s %8.1f us  %6.1f TF (fp32-equivalent)  %7.1f TF of bf16 MFMA work"
-                  % (B, ci, co, k, us, fl / us / 1e6, (6 if "split" in k else 0) * fl / us / 1e6))
+            if "absmax" in k:
+                n = (x if k.endswith("x") else y).numel() * 4
+                print("B=%d %3d->%3d @%dx%d %-15s %8.1f us  %6.2f TB/s" % (B, ci, co, H, W, k, us, n / us / 1e6))
+                continue
+            nprod = 6 if "bf16x3" in k else (3 if "fp16x2" in k else 0)
+            print("B=%d %3d->%3d @%dx%d %-15s %8.1f us  %6.1f TF (fp32-equivalent)  %7.1f TF of 16-bit MFMA work"
+                  % (B, ci, co, H, W, k, us, fl / us / 1e6, nprod * fl / us / 1e6))
+        del x, y
 
 
 if __name__ == "__main__":
