@@ -19,9 +19,18 @@ static int check_geom(const ConvGeom& g) {
     return DASR_OK;
 }
 
+static int conv2d_fwd_dispatch(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
+                               float* y, int act, int ps_r, void* stream) {
+    if (conv_mfma_supported(g)) return conv_mfma_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
+    if (conv_c1_supported(g) && ps_r == 1 && !residual) return conv_c1_fwd(g, x, w, bias, y, act, stream);
+    if (conv9_mfma_supported(g) && act == DASR_ACT_NONE && ps_r == 1 && !residual)
+        return conv9_mfma_fwd(g, x, w, bias, y, stream);
+    if (conv_gather_fwd_supported(g) && ps_r == 1 && !residual) return conv_gather_fwd(g, x, w, bias, y, act, stream);
+    return conv_direct_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
+}
 extern "C" int dasr_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                               int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
-                               int pad, int transposed, int act, int ps_r, void* stream) {
+                               float* y_amax, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                               int stride, int pad, int transposed, int act, int ps_r, void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(w); DASR_CHECK_PTR(y);
     ConvGeom g{B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, transposed};
     int rc = check_geom(g);
@@ -29,12 +38,14 @@ extern "C" int dasr_conv2d_fwd(const float* x, const float* w, const float* bias
     if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
     if (ps_r < 1) ps_r = 1;
     if (ps_r > 1 && (Cout % (ps_r * ps_r)) != 0) return DASR_E_SHAPE;
-    if (conv_mfma_supported(g)) return conv_mfma_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
-    if (conv_c1_supported(g) && ps_r == 1 && !residual) return conv_c1_fwd(g, x, w, bias, y, act, stream);
-    if (conv9_mfma_supported(g) && act == DASR_ACT_NONE && ps_r == 1 && !residual)
-        return conv9_mfma_fwd(g, x, w, bias, y, stream);
-    if (conv_gather_fwd_supported(g) && ps_r == 1 && !residual) return conv_gather_fwd(g, x, w, bias, y, act, stream);
-    return conv_direct_fwd(g, x, w, bias, residual, y, act, ps_r, stream);
+    if (!y_amax) return conv2d_fwd_dispatch(g, x, w, bias, residual, y, act, ps_r, stream);
+    // max |y| for the consumer's fp16 x 2 split convolution: the mask layer's kernel tracks it while it stores (the one
+    // producer of such a tensor on this entry point in the net); every other kernel is followed by a pass over y
+    if (!conv_mfma_supported(g) && conv_c1_supported(g) && ps_r == 1 && !residual)
+        return conv_c1_fwd(g, x, w, bias, y, act, stream, y_amax);
+    rc = conv2d_fwd_dispatch(g, x, w, bias, residual, y, act, ps_r, stream);
+    if (rc) return rc;
+    return absmax_raise(y, (size_t)B * Ho * Wo * Cout, y_amax, stream);
 }
 
 // conv 3x3 / stride 1 / pad 1 (+bias) and the InstanceNorm statistics of its output in one pass (the DGB convs)
@@ -55,20 +66,20 @@ extern "C" int dasr_conv2d_fwd_stats(const float* x, const float* w, const float
     if (rc) return rc;
     if (workspace_bytes < dasr_conv2d_fwd_stats_workspace(B, H, W, Cin, Cout)) return DASR_E_WORKSPACE;
     if (conv_mfma_fwd_stats_supported(g)) return conv_mfma_fwd_stats(g, x, w, bias, y, mean, var, workspace, stream);
-    rc = dasr_conv2d_fwd(x, w, bias, nullptr, y, B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 0, DASR_ACT_NONE, 1, stream);
+    rc = dasr_conv2d_fwd(x, w, bias, nullptr, y, nullptr, B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 0, DASR_ACT_NONE, 1, stream);
     if (rc) return rc;
     return dasr_instnorm_stats(y, mean, var, workspace, workspace_bytes, B, H * W, Cout, stream);
 }
 
-extern "C" int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, int B, int Ho, int Wo, int Cout,
-                                        int act, int ps_r, void* stream) {
+extern "C" int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, float* dconv_amax, int B, int Ho, int Wo,
+                                        int Cout, int act, int ps_r, void* stream) {
     DASR_CHECK_PTR(dy); DASR_CHECK_PTR(y); DASR_CHECK_PTR(dconv);
     DASR_CHECK_SHAPE(B > 0 && Ho > 0 && Wo > 0 && Cout > 0);
     if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
     if (ps_r < 1) ps_r = 1;
     if (ps_r > 1 && (Cout % (ps_r * ps_r)) != 0) return DASR_E_SHAPE;
     ConvGeom g{B, Ho, Wo, 1, Ho, Wo, Cout, 1, 1, 1, 0, 0};
-    return conv_epilogue_bwd(g, dy, y, dconv, act, ps_r, stream);
+    return conv_epilogue_bwd(g, dy, y, dconv, act, ps_r, stream, dconv_amax);
 }
 
 extern "C" int dasr_conv2d_dgrad(const float* dconv, const float* w, float* dx, int accumulate, int B, int H, int W,

@@ -42,7 +42,7 @@ __device__ __forceinline__ void c1_stage_rows(const float* __restrict__ x, float
 template <typename T, int CIN>
 __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int B,
-                                                        int H, int W, int Cout, int act) {
+                                                        int H, int W, int Cout, int act, float* __restrict__ amax) {
     DASR_DYN_SMEM(smem);
     float* sRow = (float*)smem;                    // [3][(W+2)*CIN]
     const int nq = Cout / 4;                       // channel quads
@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict_
     const float slope = act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
     const bool relu = act == DASR_ACT_RELU;
     auto neg = [&](float v) { return relu ? 0.f : slope * v; };
+    float om = 0.f;                                // running max |y| of this lane (amax != null)
     for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
         const int b = row / H, py = row - b * H;
         __syncthreads();
@@ -75,8 +76,10 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict_
             acc.x = acc.x > 0.f ? acc.x : neg(acc.x); acc.y = acc.y > 0.f ? acc.y : neg(acc.y);
             acc.z = acc.z > 0.f ? acc.z : neg(acc.z); acc.w = acc.w > 0.f ? acc.w : neg(acc.w);
             st4(yrow + (size_t)px * Cout, acc);
+            om = dasr_amax4(om, acc);
         }
     }
+    if (amax) dasr_amax_commit(amax, om);
 }
 
 // dw[tap][co] = sum_p x[p+tap] * dconv[p][co], dbias[co] = sum_p dconv[p][co], dconv = dy * act'(y)
@@ -191,16 +194,18 @@ bool conv_c1_supported(const ConvGeom& g) {
            g.W == g.Wo && g.W <= C1_MAXW;
 }
 template <typename T>
-static int conv_c1_fwd_impl(const ConvGeom& g, const float* x, const float* w, const float* bias, T* y, int act, void* stream) {
+static int conv_c1_fwd_impl(const ConvGeom& g, const float* x, const float* w, const float* bias, T* y, int act, void* stream,
+                            float* amax = nullptr) {
     unsigned grid = (unsigned)(g.B * g.H);
     if (grid > 256 * 8) grid = 256 * 8;
     const size_t lds = sizeof(float) * 3 * (g.W + 2) * g.Cin;
-    if (g.Cin == 3) DASR_LAUNCH((k_conv3x3_c1_fwd<T, 3>), dim3(grid), dim3(256), lds, stream, x, w, bias, y, g.B, g.H, g.W, g.Cout, act);
-    else            DASR_LAUNCH((k_conv3x3_c1_fwd<T, 1>), dim3(grid), dim3(256), lds, stream, x, w, bias, y, g.B, g.H, g.W, g.Cout, act);
+    if (g.Cin == 3) DASR_LAUNCH((k_conv3x3_c1_fwd<T, 3>), dim3(grid), dim3(256), lds, stream, x, w, bias, y, g.B, g.H, g.W, g.Cout, act, amax);
+    else            DASR_LAUNCH((k_conv3x3_c1_fwd<T, 1>), dim3(grid), dim3(256), lds, stream, x, w, bias, y, g.B, g.H, g.W, g.Cout, act, amax);
     DASR_RETURN_LAUNCH_STATUS();
 }
-int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream) {
-    return conv_c1_fwd_impl<float>(g, x, w, bias, y, act, stream);
+int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream,
+                float* amax) {
+    return conv_c1_fwd_impl<float>(g, x, w, bias, y, act, stream, amax);
 }
 int conv_c1_fwd_bf16(const ConvGeom& g, const float* x, const float* w, const float* bias, bf16_t* y, int act, void* stream) {
     return conv_c1_fwd_impl<bf16_t>(g, x, w, bias, y, act, stream);

@@ -51,15 +51,19 @@ __global__ void __launch_bounds__(256) k_conv_direct_fwd(ConvGeom g, const float
 template <typename T>
 __global__ void __launch_bounds__(256) k_conv_epilogue_bwd(ConvGeom g, const T* __restrict__ dy,
                                                            const T* __restrict__ y, T* __restrict__ dconv,
-                                                           int act, int ps_r) {
+                                                           int act, int ps_r, float* __restrict__ amax) {
     size_t n = (size_t)g.B * g.Ho * g.Wo * g.Cout;
+    float om = 0.f;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         int co = (int)(idx % g.Cout);
         size_t pix = idx / g.Cout;
         int ox = (int)(pix % g.Wo), oy = (int)((pix / g.Wo) % g.Ho), b = (int)(pix / ((size_t)g.Wo * g.Ho));
         size_t o = conv_out_index(g, b, oy, ox, co, ps_r);
-        st1(dconv + idx, ld1(dy + o) * dasr_act_grad_from_out(ld1(y + o), act));
+        const float v = ld1(dy + o) * dasr_act_grad_from_out(ld1(y + o), act);
+        st1(dconv + idx, v);
+        om = dasr_amax1(om, v);
     }
+    if (amax) dasr_amax_commit(amax, om);
 }
 
 // ------------------------------------------------------------------------------------------ dgrad
@@ -188,21 +192,28 @@ int conv_direct_fwd(const ConvGeom& g, const float* x, const float* w, const flo
 // No PixelShuffle: the index map is the identity -> float4 streaming.
 template <typename T>
 __global__ void __launch_bounds__(256) k_conv_epilogue_bwd_flat4(const T* __restrict__ dy, const T* __restrict__ y,
-                                                                 T* __restrict__ dconv, size_t n4, int act) {
+                                                                 T* __restrict__ dconv, size_t n4, int act,
+                                                                 float* __restrict__ amax) {
+    float om = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 d = ld4(dy + 4 * i), v = ld4(y + 4 * i);
-        st4(dconv + 4 * i, make_float4(d.x * dasr_act_grad_from_out(v.x, act), d.y * dasr_act_grad_from_out(v.y, act),
-                                       d.z * dasr_act_grad_from_out(v.z, act), d.w * dasr_act_grad_from_out(v.w, act)));
+        const float4 o = make_float4(d.x * dasr_act_grad_from_out(v.x, act), d.y * dasr_act_grad_from_out(v.y, act),
+                                     d.z * dasr_act_grad_from_out(v.z, act), d.w * dasr_act_grad_from_out(v.w, act));
+        st4(dconv + 4 * i, o);
+        om = dasr_amax4(om, o);
     }
+    if (amax) dasr_amax_commit(amax, om);
 }
 // PixelShuffle(R): one thread per (conv pixel, shuffled channel c): R*R coalesced 4-byte reads of dy / y (consecutive
 // lanes = consecutive c), one contiguous run of R*R floats written (co = c*R*R + i*R + j).  blockIdx.y = conv row
 // (b*Ho + oy), so the only division left is e / Cq.
 template <int R, typename T>
 __global__ void __launch_bounds__(256) k_conv_epilogue_bwd_ps(const T* __restrict__ dy, const T* __restrict__ y,
-                                                              T* __restrict__ dconv, int Wo, int Cq, int act) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= Wo * Cq) return;
+                                                              T* __restrict__ dconv, int Wo, int Cq, int act,
+                                                              float* __restrict__ amax) {
+    const int e0 = blockIdx.x * 256 + threadIdx.x;
+    const bool livee = e0 < Wo * Cq;                                      // (no early return: the wave meets in dasr_amax_commit)
+    const int e = livee ? e0 : Wo * Cq - 1;
     const int ox = e / Cq, c = e - ox * Cq;
     const size_t row = blockIdx.y;                                        // b*Ho + oy
     const size_t srow = (size_t)Wo * R * Cq;                              // floats per shuffled row
@@ -217,35 +228,45 @@ __global__ void __launch_bounds__(256) k_conv_epilogue_bwd_ps(const T* __restric
             out[i * R + j] = ld1(dyp + o) * dasr_act_grad_from_out(ld1(yp + o), act);
         }
     T* dst = dconv + (row * Wo + ox) * (size_t)(Cq * R * R) + (size_t)c * (R * R);
-    if (R == 2) {
-        st4(dst, make_float4(out[0], out[1], out[2], out[3]));
-    } else {
+    if (livee) {
+        if (R == 2) {
+            st4(dst, make_float4(out[0], out[1], out[2], out[3]));
+        } else {
 #pragma unroll
-        for (int q = 0; q < R * R; ++q) st1(dst + q, out[q]);
+            for (int q = 0; q < R * R; ++q) st1(dst + q, out[q]);
+        }
+    }
+    if (amax) {
+        float om = 0.f;
+#pragma unroll
+        for (int q = 0; q < R * R; ++q) om = dasr_amax1(om, out[q]);
+        dasr_amax_commit(amax, om);
     }
 }
 
 template <typename T>
-static int conv_epilogue_bwd_impl(const ConvGeom& g, const T* dy, const T* y, T* dconv, int act, int ps_r, void* stream) {
+static int conv_epilogue_bwd_impl(const ConvGeom& g, const T* dy, const T* y, T* dconv, int act, int ps_r, void* stream,
+                                  float* amax = nullptr) {
     size_t n = (size_t)g.B * g.Ho * g.Wo * g.Cout;
     const size_t rows = (size_t)g.B * g.Ho;
     if (ps_r <= 1 && (n % 4) == 0) {
-        DASR_LAUNCH((k_conv_epilogue_bwd_flat4<T>), dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, dy, y, dconv, n / 4, act);
+        DASR_LAUNCH((k_conv_epilogue_bwd_flat4<T>), dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, dy, y, dconv, n / 4, act, amax);
     } else if ((ps_r == 2 || ps_r == 3) && (g.Cout % (ps_r * ps_r)) == 0 && rows <= 65535 &&
                (size_t)g.Wo * (g.Cout / (ps_r * ps_r)) < (1u << 30)) {
         const int Cq = g.Cout / (ps_r * ps_r);
         const dim3 grid(dasr_cdiv((size_t)g.Wo * Cq, 256), (unsigned)rows);
         if (ps_r == 2)
-            DASR_LAUNCH((k_conv_epilogue_bwd_ps<2, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act);
+            DASR_LAUNCH((k_conv_epilogue_bwd_ps<2, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act, amax);
         else
-            DASR_LAUNCH((k_conv_epilogue_bwd_ps<3, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act);
+            DASR_LAUNCH((k_conv_epilogue_bwd_ps<3, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act, amax);
     } else {
-        DASR_LAUNCH((k_conv_epilogue_bwd<T>), dim3(dasr_ew_grid(n)), dim3(256), 0, stream, g, dy, y, dconv, act, ps_r);
+        DASR_LAUNCH((k_conv_epilogue_bwd<T>), dim3(dasr_ew_grid(n)), dim3(256), 0, stream, g, dy, y, dconv, act, ps_r, amax);
     }
     DASR_RETURN_LAUNCH_STATUS();
 }
-int conv_epilogue_bwd(const ConvGeom& g, const float* dy, const float* y, float* dconv, int act, int ps_r, void* stream) {
-    return conv_epilogue_bwd_impl<float>(g, dy, y, dconv, act, ps_r, stream);
+int conv_epilogue_bwd(const ConvGeom& g, const float* dy, const float* y, float* dconv, int act, int ps_r, void* stream,
+                      float* amax) {
+    return conv_epilogue_bwd_impl<float>(g, dy, y, dconv, act, ps_r, stream, amax);
 }
 int conv_epilogue_bwd_bf16(const ConvGeom& g, const bf16_t* dy, const bf16_t* y, bf16_t* dconv, int act, int ps_r,
                            void* stream) {

@@ -21,7 +21,7 @@ __host__ __device__ __forceinline__ size_t conv_out_index(const ConvGeom& g, int
 int conv_direct_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, const float* residual,
                     float* y, int act, int ps_r, void* stream);
 int conv_epilogue_bwd(const ConvGeom& g, const float* dy, const float* y, float* dconv, int act, int ps_r,
-                      void* stream);
+                      void* stream, float* amax = nullptr);
 int conv_direct_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
 int conv_direct_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* stream);
 int conv_colsum(const float* m, float* out, size_t rows, int C, void* stream);
@@ -64,7 +64,11 @@ int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* st
 
 // conv_c1.hip (3x3, Cin == 1: SEAN.mlp_mask on the depth map)
 bool conv_c1_supported(const ConvGeom& g);
-int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream);
+int conv_c1_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, int act, void* stream,
+                float* amax = nullptr);
+// (conv_split_bf16.hip) raise *amax to max |x| over n floats without clearing it first - the follow-up pass of entry points
+// whose kernel does not track the maximum of what it stores itself
+int absmax_raise(const float* x, size_t n, float* amax, void* stream);
 int conv_c1_wgrad(const ConvGeom& g, const float* x, const float* dy, const float* yact, int act, float* dw, float* dbias,
                   void* stream);
 

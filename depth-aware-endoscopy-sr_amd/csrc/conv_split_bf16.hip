@@ -62,6 +62,7 @@ struct ConvSplitArgs {
     int tiles_x, tiles_y, nsl, nitems, Q, G8;
     const float* xmax;       // NP = 2: max |x| and max |w| in device memory (dasr_absmax); NP = 3: unused
     const float* wmax;
+    float* ymax;             // (may be null) raised to max |y| of what the epilogue stores
 };
 
 template <int N>
@@ -69,6 +70,16 @@ __device__ __forceinline__ void sp_wait_vm() {
 #ifndef DASR_HIPEMU
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #endif
+}
+
+// the same with a count that constant-folds after unrolling (a wave's slice-piece count is a run-time, wave-uniform value)
+__device__ __forceinline__ void sp_wait_vm_n(int n) {
+    switch (n) {
+#define SP_W(N) case N: sp_wait_vm<N>(); break;
+        SP_W(0) SP_W(1) SP_W(2) SP_W(3) SP_W(4) SP_W(5) SP_W(6) SP_W(7) SP_W(8) SP_W(9) SP_W(10) SP_W(11) SP_W(12)
+#undef SP_W
+        default: sp_wait_vm<0>(); break;
+    }
 }
 
 // x = a0 + a1 + a2 exactly (each piece the bf16 rounding of what the previous ones left)
@@ -157,7 +168,7 @@ __device__ __forceinline__ SpScale sp_scales(const float* xmax, const float* wma
 template <int NT, int NP>
 __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][NT], const ConvSplitArgs& a, char* const scr, const float* sBias,
                                             const float inv, const int x0, const int y0, const int n0, const int bb,
-                                            const int wv, const int lane, const int li, const int lh) {
+                                            const int wv, const int lane, const int li, const int lh, float& om) {
     const int wvalid = a.W - x0;
     const bool is_relu = a.act == DASR_ACT_RELU;
     const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
@@ -205,6 +216,7 @@ __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][NT], const ConvSpli
                         }
                         *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
                         *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                        om = dasr_amax4(dasr_amax4(om, make_float4(o[0], o[1], o[2], o[3])), make_float4(o[4], o[5], o[6], o[7]));
                     }
                 } else {
                     // PixelShuffle(2): out[b, 2gy+i, 2gx+j, c] = conv[b, gy, gx, 4c + 2i + j]: 8 values of c per (pixel, sub-pixel)
@@ -224,6 +236,7 @@ __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][NT], const ConvSpli
                                     (n0 + 32 * n) / 4;
                         *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
                         *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                        om = dasr_amax4(dasr_amax4(om, make_float4(o[0], o[1], o[2], o[3])), make_float4(o[4], o[5], o[6], o[7]));
                     }
                 }
             }
@@ -241,8 +254,12 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     constexpr int W1 = WP >= 512 ? 8 : WP / 64;                              // waves 0 .. W1-1 carry pieces 0 .. 511
     constexpr int W2 = WP > 512 ? (WP - 512) / 64 : 0;                       // waves 0 .. W2-1 a second one (pieces 512 ..)
     char* const sH = smem;                              // [2][SP_HBYTES]
-    char* const sW = smem + 2 * SP_HBYTES;              // [3][SLAB]
-    float* const sBias = (float*)(sW + 3 * SLAB);       // [Cout]
+    // kernel slices: a ring of R slots running D steps ahead of the MFMAs.  (Measured for NP = 2, whose 8 KB slices would
+    // leave room for conv_bf16_v2.hip's nine slots / five steps ahead: no change on any shape - the slices are not what a
+    // step waits for.)
+    constexpr int R = 3, D = 2;
+    char* const sW = smem + 2 * SP_HBYTES;              // [R][SLAB]
+    float* const sBias = (float*)(sW + R * SLAB);       // [Cout]
     const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
     const int li = lane & 31, lh = lane >> 5;
     // DMA pieces of a kernel slice per thread, NP = 3: NT = 4: 768 = 512 + 256 (waves 0-3 two, waves 4-7 one); NT = 2: 384
@@ -301,7 +318,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     // slice of K-step (slice index ns, tap, chunk cc): contiguous SLAB bytes at ((ns * 9 + tap) * NC + cc) * SLAB
     auto w_issue = [&](int cc, int tap, int fn0) {
         const char* src = (const char*)a.ws + (size_t)(((fn0 / NTILE) * 9 + tap) * NC + cc) * SLAB + 16 * tid;
-        const dasr_lds_addr_t dst = ldsW + (tap % 3) * SLAB;
+        const dasr_lds_addr_t dst = ldsW + (tap % R) * SLAB;
         if (wv < W1) DASR_GLDS16(src, dst);                                             // pieces 0 .. 511 (or fewer)
         if (wv < W2) DASR_GLDS16(src + 16 * SP_NTHR, dst + 1024 * SP_NWV);              // pieces 512 .. 767
     };
@@ -310,11 +327,12 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4);
 
     int par = 0;
+    float om = 0.f;                                     // running max |y| of this lane (a.ymax)
     halo_setup(x0, y0, bb, true);
 #pragma unroll
     for (int u = 0; u < SP_NHP; ++u) halo_issue(u, 0, 0);
-    w_issue(0, 0, n0);
-    w_issue(0, 1, n0);
+#pragma unroll
+    for (int t = 0; t < D; ++t) w_issue(0, t, n0);
 
     for (;;) {
         const int nitem = item + a.G8;
@@ -343,20 +361,22 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
             const char* const hb = sH + par * SP_HBYTES;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                // all but the operations of the previous step (its halo piece, this wave's pieces of W(step + 1)) are done
+                // the slice of this step (issued D steps ago) and this chunk's halo pieces have landed once all but the
+                // operations this wave issued in the last D - 1 steps (a halo piece in the steps of taps 0 .. 4, nwq slice
+                // pieces in every step) are done
                 {
-                    const int h = ((tap + 8) % 9) < SP_NHP ? 1 : 0;
-                    if (nwq == 2)      { if (h) sp_wait_vm<3>(); else sp_wait_vm<2>(); }
-                    else if (nwq == 1) { if (h) sp_wait_vm<2>(); else sp_wait_vm<1>(); }
-                    else               { if (h) sp_wait_vm<1>(); else sp_wait_vm<0>(); }
+                    int nh = 0;
+#pragma unroll
+                    for (int k = 1; k < D; ++k) nh += ((tap - k + 9) % 9) < SP_NHP ? 1 : 0;
+                    sp_wait_vm_n(nh + (D - 1) * nwq);
                 }
                 DASR_RAW_BARRIER();
                 if (tap < SP_NHP) halo_issue(tap, fcc, par ^ 1);
-                if (tap + 2 < 9) w_issue(cc, tap + 2, n0);
-                else             w_issue(fcc, tap + 2 - 9, last ? nn0 : n0);
+                if (tap + D < 9) w_issue(cc, tap + D, n0);
+                else             w_issue(fcc, tap + D - 9, last ? nn0 : n0);
 
                 const int dy = tap / 3, dx = tap - 3 * dy;
-                const char* const wb = sW + (tap % 3) * SLAB + boff;
+                const char* const wb = sW + (tap % R) * SLAB + boff;
                 int Pq = Pl;
 #ifndef DASR_HIPEMU
                 asm volatile("" : "+v"(Pq));
@@ -389,11 +409,12 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
         // accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue
         DASR_RAW_BARRIER();
         char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
-        sp_epilogue<NT, NP>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh);
+        sp_epilogue<NT, NP>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh, om);
         if (!has_next) break;
         item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
     }
     sp_wait_vm<0>();
+    if (a.ymax) dasr_amax_commit(a.ymax, om);
 }
 
 // ---- 32 produced channels (the HR tail: 32 -> 32, 64 -> 32, and the dgrads of 32 -> 32 / 32 -> 128).  With one 32-channel tile a
@@ -483,6 +504,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
     const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4);
 
     int par = 0;
+    float om = 0.f;                                     // running max |y| of this lane (a.ymax)
     halo_setup(x0, y0, bb, true);
     chunk_issue(0, n0, 0);
 
@@ -545,11 +567,12 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
         // accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue
         DASR_RAW_BARRIER();
         char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
-        sp_epilogue<NT, NP>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh);
+        sp_epilogue<NT, NP>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh, om);
         if (!has_next) break;
         item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
     }
     sp_wait_vm<0>();
+    if (a.ymax) dasr_amax_commit(a.ymax, om);
 }
 
 // ---- the kernel split: fp32 packed [2][9][Cin][Cout] (plane 0 = HWIO) -> 16-bit image of both modes
@@ -649,17 +672,21 @@ static bool sp_ok(int H, int W, int K, int N) {
 extern "C" int dasr_conv3x3_split_supported(int H, int W, int Cin, int Cout) {
     return (sp_ok(H, W, Cin, Cout) && sp_ok(H, W, Cout, Cin)) ? 1 : 0;      // forward and dgrad
 }
-extern "C" int dasr_absmax(const float* x, size_t n, float* amax, void* stream) {
+int absmax_raise(const float* x, size_t n, float* amax, void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(amax);
     DASR_CHECK_SHAPE(n > 0 && (((size_t)x) & 15) == 0);
-    hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
     const size_t n4 = n / 4;
     size_t g = (n4 + 256 * 8 - 1) / (256 * 8);           // ~8 float4 per thread
     if (g > 2048) g = 2048;
     if (g < 1) g = 1;
     DASR_LAUNCH(k_absmax, dim3((unsigned)g), dim3(256), 0, stream, x, n4, n, (unsigned*)amax);
     DASR_RETURN_LAUNCH_STATUS();
+}
+extern "C" int dasr_absmax(const float* x, size_t n, float* amax, void* stream) {
+    DASR_CHECK_PTR(amax);
+    hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return absmax_raise(x, n, amax, stream);
 }
 extern "C" size_t dasr_conv3x3_split_weights_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0) return 0;
@@ -703,26 +730,27 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
     DASR_RETURN_LAUNCH_STATUS();
 }
 static int sp_fwd(const float* x, const float* xmax, const unsigned short* w_split, const float* wmax, const float* bias,
-                  const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int act, int ps_r, void* stream) {
+                  const float* residual, float* y, float* ymax, int B, int H, int W, int Cin, int Cout, int act, int ps_r,
+                  void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(w_split); DASR_CHECK_PTR(y);
     DASR_CHECK_SHAPE(B > 0);
     if (!dasr_conv3x3_split_supported(H, W, Cin, Cout)) return DASR_E_UNSUPPORTED;
     if (act < 0 || act > 2) return DASR_E_UNSUPPORTED;
     if (ps_r < 1) ps_r = 1;
     if (ps_r > 2 || (ps_r == 2 && (residual != nullptr || (Cout % 128) != 0))) return DASR_E_UNSUPPORTED;
-    ConvSplitArgs a{x, (const bf16_t*)w_split, bias, residual, y, B, H, W, Cin, Cout, 0, act, ps_r, 0, 0, 0, 0, 0, 0, xmax, wmax};
+    ConvSplitArgs a{x, (const bf16_t*)w_split, bias, residual, y, B, H, W, Cin, Cout, 0, act, ps_r, 0, 0, 0, 0, 0, 0, xmax, wmax, ymax};
     return xmax ? sp_launch<2>(a, stream) : sp_launch<3>(a, stream);
 }
 extern "C" int dasr_conv3x3_fwd_split(const float* x, const unsigned short* w_split, const float* bias,
                                       const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int act,
                                       int ps_r, void* stream) {
-    return sp_fwd(x, nullptr, w_split, nullptr, bias, residual, y, B, H, W, Cin, Cout, act, ps_r, stream);
+    return sp_fwd(x, nullptr, w_split, nullptr, bias, residual, y, nullptr, B, H, W, Cin, Cout, act, ps_r, stream);
 }
 extern "C" int dasr_conv3x3_fwd_split2(const float* x, const float* xmax, const unsigned short* w_split, const float* wmax,
-                                       const float* bias, const float* residual, float* y, int B, int H, int W, int Cin,
-                                       int Cout, int act, int ps_r, void* stream) {
+                                       const float* bias, const float* residual, float* y, float* y_amax, int B, int H,
+                                       int W, int Cin, int Cout, int act, int ps_r, void* stream) {
     DASR_CHECK_PTR(xmax); DASR_CHECK_PTR(wmax);
-    return sp_fwd(x, xmax, w_split, wmax, bias, residual, y, B, H, W, Cin, Cout, act, ps_r, stream);
+    return sp_fwd(x, xmax, w_split, wmax, bias, residual, y, y_amax, B, H, W, Cin, Cout, act, ps_r, stream);
 }
 // dx[p, ci] (+)= sum_{tap, co} dconv[p - off(tap), co] * w[tap][ci][co]: mode 1 of the split image (taps already flipped)
 static int sp_dgrad(const float* dconv, const float* dmax, const unsigned short* w_split, const float* wmax, float* dx,
@@ -732,7 +760,7 @@ static int sp_dgrad(const float* dconv, const float* dmax, const unsigned short*
     if (!dasr_conv3x3_split_supported(H, W, Cin, Cout)) return DASR_E_UNSUPPORTED;
     const size_t mode1 = (size_t)9 * (dmax ? 2 : 3) * Cin * Cout;
     ConvSplitArgs a{dconv, (const bf16_t*)w_split + mode1, nullptr, nullptr, dx, B, H, W, Cout, Cin,
-                    accumulate, DASR_ACT_NONE, 1, 0, 0, 0, 0, 0, 0, dmax, wmax};
+                    accumulate, DASR_ACT_NONE, 1, 0, 0, 0, 0, 0, 0, dmax, wmax, nullptr};
     return dmax ? sp_launch<2>(a, stream) : sp_launch<3>(a, stream);
 }
 extern "C" int dasr_conv3x3_dgrad_split(const float* dconv, const unsigned short* w_split, float* dx, int accumulate, int B,

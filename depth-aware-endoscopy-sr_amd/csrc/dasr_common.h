@@ -84,6 +84,26 @@ static inline unsigned dasr_ew_grid(size_t n, unsigned block = 256) {
     return (unsigned)g;
 }
 
+// ---- max |.| bookkeeping for the fp16 x 2 split convolutions (conv_split_bf16.hip).  A kernel that PRODUCES a tensor one of
+// them reads keeps a running maximum of the magnitudes it stores (one register per lane) and raises the caller's word
+// once per wave when it is done: the consumer's power-of-two scale then costs no pass over the tensor.  Contract of every
+// `amax` argument: device memory, zero (or any lower bound) on entry, raised atomically - non-negative floats order like
+// their bits.  Values a kernel computes for clamped / shadow lanes are duplicates of stored ones and may take part.
+__device__ __forceinline__ float dasr_amax1(float m, float v) { return fmaxf(m, fabsf(v)); }
+__device__ __forceinline__ float dasr_amax4(float m, float4 o) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+}
+// every lane of the wave must arrive (no early-exited lanes): butterfly over the 64 lanes, one atomic per wave
+__device__ __forceinline__ void dasr_amax_commit(float* amax, float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        unsigned u;
+        memcpy(&u, &m, 4);
+        atomicMax((unsigned*)amax, u);
+    }
+}
+
 __device__ __forceinline__ float dasr_act(float v, int act) {
     if (act == DASR_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == DASR_ACT_LRELU02) return v > 0.f ? v : 0.2f * v;

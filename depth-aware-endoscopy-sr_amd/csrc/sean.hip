@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const T* __restric
                                                   const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
                                                   const float* __restrict__ alpha_b, const T* __restrict__ residual,
                                                   T* __restrict__ out, int relu, float eps,
-                                                  const int* __restrict__ onehot_flag) {
+                                                  const int* __restrict__ onehot_flag, float* __restrict__ amax) {
     if (onehot_flag && *onehot_flag == 0) return;   // one-hot masks: k_sean_fwd_onehot does the work
     DASR_DYN_SMEM(smem);
     float* sD = (float*)smem;
@@ -93,12 +93,14 @@ __global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const T* __restric
     __syncthreads();
     int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
     int c = c0 + cl;
-    if (c >= g.C) return;
+    const bool livec = c < g.C;                      // (no early return: the wave meets again in dasr_amax_commit)
+    if (!livec) c = 0;
     float a_g = alpha_g[0], a_b = alpha_b[0];
     float mu = mean[(size_t)b * g.C + c];
     float s = dasr_double_in_scale(var[(size_t)b * g.C + c], eps);
     float bg = bias_g[c], bb = bias_b[c];
-    for (int lp = pl; lp < SEAN_TH * SEAN_TW; lp += 4) {
+    float om = 0.f;
+    for (int lp = pl; livec && lp < SEAN_TH * SEAN_TW; lp += 4) {
         int ly = lp / SEAN_TW, lx = lp % SEAN_TW;
         int y = y0 + ly, x = x0 + lx;
         if (y >= g.H || x >= g.W) continue;
@@ -115,7 +117,9 @@ __global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const T* __restric
         if (residual) o += ld1(residual + p * g.C + c);
         if (relu) o = o > 0.f ? o : 0.f;
         st1(out + p * g.C + c, o);
+        om = dasr_amax1(om, o);
     }
+    if (amax) dasr_amax_commit(amax, om);
 }
 
 // ---------------------------------------------------------------------------------------- backward
@@ -137,7 +141,8 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restr
                                                     float* __restrict__ dbias_g, float* __restrict__ dbias_b,
                                                     float* __restrict__ dalpha_g, float* __restrict__ dalpha_b,
                                                     T* __restrict__ dres, float* __restrict__ S, int relu,
-                                                    float eps, const int* __restrict__ onehot_flag) {
+                                                    float eps, const int* __restrict__ onehot_flag,
+                                                    float* __restrict__ dgb2_amax) {
     if (onehot_flag && *onehot_flag == 0) return;
     DASR_DYN_SMEM(smem);
     float* sD = (float*)smem;
@@ -159,6 +164,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restr
     float s = live ? dasr_double_in_scale(var[(size_t)b * g.C + c], eps) : 0.f;
     float bg = live ? bias_g[c] : 0.f, bb = live ? bias_b[c] : 0.f;
     float S1 = 0.f, S2 = 0.f, dag = 0.f, dab = 0.f, dbg = 0.f, dbb = 0.f;
+    float gm = 0.f;                                  // running max |dgb2| of this lane
     int MW = SEAN_TW + 2, MH = SEAN_TH + 2;
     if (live)
         for (int lp = pl; lp < SEAN_TH * SEAN_TW; lp += 4) {
@@ -180,6 +186,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restr
             float dgam = g0 * xh, dbet = g0;
             st1(dgb2 + p * 2 * g.C + c, (1.f - a_g) * dgam);
             st1(dgb2 + p * 2 * g.C + g.C + c, (1.f - a_b) * dbet);
+            gm = dasr_amax1(dasr_amax1(gm, (1.f - a_g) * dgam), (1.f - a_b) * dbet);
             dag = fmaf(dgam, g1 - g2, dag);
             dab = fmaf(dbet, b1 - b2, dab);
             float dg1 = a_g * dgam, db1 = a_b * dbet;
@@ -234,6 +241,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restr
         float v = sdD[i];
         if (c0 + cl2 < g.C && v != 0.f) atomicAdd(&dD[((size_t)b * 18 * K + r) * g.C + c0 + cl2], v);
     }
+    if (dgb2_amax) dasr_amax_commit(dgb2_amax, gm);
 }
 
 // dt = s*(dxhat - S1/N) + s'(var)*(2/N)*(t-mean)*S2; float4 per lane when C % 4 == 0 (per-(b,c) constants are
@@ -241,8 +249,10 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restr
 template <typename T>
 __global__ void __launch_bounds__(256) k_sean_bwd_b(const T* __restrict__ t, const float* __restrict__ mean,
                                                     const float* __restrict__ var, const float* __restrict__ S,
-                                                    T* __restrict__ dt, int HW, int C, size_t n, float eps) {
+                                                    T* __restrict__ dt, int HW, int C, size_t n, float eps,
+                                                    float* __restrict__ amax) {
     const float invN = 1.0f / (float)HW;
+    float om = 0.f;
     if ((C & 3) == 0) {
         const size_t n4 = n >> 2;
         const int C4 = C >> 2;
@@ -263,7 +273,9 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const T* __restrict__ t, con
             dv.w = dasr_double_in_scale(vr.w, eps) * (dv.w - s23.z * invN) +
                    dasr_double_in_dscale(vr.w, eps) * 2.f * invN * (tv.w - mu.w) * s23.w;
             st4(dt + 4 * i, dv);
+            om = dasr_amax4(om, dv);
         }
+        if (amax) dasr_amax_commit(amax, om);
         return;
     }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -273,8 +285,11 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const T* __restrict__ t, con
         float v = var[bc];
         float s = dasr_double_in_scale(v, eps), ds = dasr_double_in_dscale(v, eps);
         float xc = ld1(t + i) - mean[bc];
-        st1(dt + i, s * (ld1(dt + i) - S[bc * 2] * invN) + ds * 2.f * invN * xc * S[bc * 2 + 1]);
+        const float o = s * (ld1(dt + i) - S[bc * 2] * invN) + ds * 2.f * invN * xc * S[bc * 2 + 1];
+        st1(dt + i, o);
+        om = dasr_amax1(om, o);
     }
+    if (amax) dasr_amax_commit(amax, om);
 }
 
 
@@ -284,7 +299,8 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const T* __restrict__ t, con
 template <typename T>
 __global__ void __launch_bounds__(256) k_sean_bwd_b_rows(const T* __restrict__ t, const float* __restrict__ mean,
                                                          const float* __restrict__ var, const float* __restrict__ S,
-                                                         T* __restrict__ dt, int HW, int C, float eps) {
+                                                         T* __restrict__ dt, int HW, int C, float eps,
+                                                         float* __restrict__ amax) {
     const int C4 = C >> 2, q = threadIdx.x % C4, pl = threadIdx.x / C4, npl = 256 / C4;
     const int b = blockIdx.y, c = 4 * q;
     const float invN = 1.0f / (float)HW;
@@ -299,6 +315,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b_rows(const T* __restrict__ t
     const float4 S1 = make_float4(s01.y, s01.w, s23.y, s23.w);
     const T* tb = t + (size_t)b * HW * C + c;
     T* db = dt + (size_t)b * HW * C + c;
+    float om = 0.f;
     for (int p = blockIdx.x * npl + pl; p < HW; p += gridDim.x * npl) {
         const float4 tv = ld4(tb + (size_t)p * C);
         float4 dv = ld4(db + (size_t)p * C);
@@ -308,7 +325,9 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b_rows(const T* __restrict__ t
         dv.z = A.z * (dv.z - Bm.z) + D2.z * (tv.z - mu.z) * S1.z;
         dv.w = A.w * (dv.w - Bm.w) + D2.w * (tv.w - mu.w) * S1.w;
         st4(db + (size_t)p * C, dv);
+        om = dasr_amax4(om, dv);
     }
+    if (amax) dasr_amax_commit(amax, om);
 }
 
 // =====================================================================================================
@@ -494,7 +513,7 @@ struct SeanTile { int b, y0, x0; };
 #ifndef DASR_SEAN_RES_OCC
 #define DASR_SEAN_RES_OCC 2
 #endif
-template <bool RELU, bool HAS_RES, typename TA>
+template <bool RELU, bool HAS_RES, typename TA, bool AMAX = false>
 __global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_fwd_onehot(SeanGeom g, const TA* __restrict__ t,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ var,
@@ -506,7 +525,8 @@ __global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_f
                                                             const float* __restrict__ alpha_g,
                                                             const float* __restrict__ alpha_b,
                                                             const TA* __restrict__ residual,
-                                                            TA* __restrict__ out, float eps, int tiles_per_wg) {
+                                                            TA* __restrict__ out, float eps, int tiles_per_wg,
+                                                            float* __restrict__ amax) {
     DASR_DYN_SMEM(smem);
     constexpr int TH = SF_TH, NG = TH;                         // NG groups of 8 pixels per wave and tile (TH/4 rows x 4)
     const int K1 = g.K + 1;
@@ -560,6 +580,7 @@ __global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_f
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int cur_b = -1;
     float4 mu = zero4, sc = zero4;
+    float om = 0.f;                                        // (AMAX) running max |out| of this lane
     for (int tt = first; tt < last; ++tt) {
         const int b = T.b, y0 = T.y0, x0 = T.x0;
         __syncthreads();                                   // previous tile is done with sR (and sD)
@@ -594,6 +615,7 @@ __global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_f
                     o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
                     o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
                 }
+                if (AMAX) om = dasr_amax4(om, o);     // (clamped / shadow lanes hold duplicates of stored values)
                 if (live && y < g.H && x < g.W) {
                     TA* dst = (TA*)(orow + ((unsigned)x * (unsigned)g.C + (unsigned)c) * (unsigned)sizeof(TA));
                     st4_nt(dst, o);       // written once, read by the next kernel from HBM: do not displace the inputs
@@ -617,6 +639,7 @@ __global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_f
         }
         consume(NG - 1, fb);
     }
+    if (AMAX) dasr_amax_commit(amax, om);
 }
 
 // ---- backward, pass A, one-hot -------------------------------------------------------------------------
@@ -687,7 +710,7 @@ __device__ __forceinline__ float4 sean_f4(float4 v) { return v; }
 __device__ __forceinline__ void sean_ldraw(const bf16_t* p, bf16x4& v) { v = *(const bf16x4*)p; }
 __device__ __forceinline__ void sean_ldraw(const float* p, float4& v) { v = *(const float4*)p; }
 
-template <typename T, int SB_TH>
+template <typename T, int SB_TH, bool AMAX = false>
 __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     SeanGeom g, const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ t,
     const float* __restrict__ mean, const float* __restrict__ var, const T* __restrict__ gb2,
@@ -695,7 +718,8 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     const float* __restrict__ bias_g, const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
     const float* __restrict__ alpha_b, T* __restrict__ dt, T* __restrict__ dgb2, float* __restrict__ dD_slabs,
     float* __restrict__ dbias_g, float* __restrict__ dbias_b, float* __restrict__ dalpha_g,
-    float* __restrict__ dalpha_b, T* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles) {
+    float* __restrict__ dalpha_b, T* __restrict__ dres, float* __restrict__ S, int relu, float eps, int ntiles,
+    float* __restrict__ dgb2_amax) {
     if (flag && *flag != 0) return;
     DASR_DYN_SMEM(smem);
     constexpr int NP = SeanBwdCfg<T>::NP;
@@ -728,6 +752,7 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
     }
     float4 S1 = zero4, S2 = zero4, dbg = zero4, dbb = zero4;
     float dag = 0.f, dab = 0.f;
+    float gm = 0.f;                                             // (AMAX) running max |dgb2| of this lane
     f32x4 acc[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q)
@@ -798,10 +823,11 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
                 const float4 xc = make_float4(tv.x - mu.x, tv.y - mu.y, tv.z - mu.z, tv.w - mu.w);
                 const float4 xh = make_float4(xc.x * sc.x, xc.y * sc.y, xc.z * sc.z, xc.w * sc.w);
                 const float4 dgam = make_float4(g0.x * xh.x, g0.y * xh.y, g0.z * xh.z, g0.w * xh.w);
-                st4(dgb2 + p * 2 * g.C + c, make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y,
-                                                        (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w));
-                st4(dgb2 + p * 2 * g.C + g.C + c, make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y,
-                                                              (1.f - a_b) * g0.z, (1.f - a_b) * g0.w));
+                const float4 dg2 = make_float4((1.f - a_g) * dgam.x, (1.f - a_g) * dgam.y, (1.f - a_g) * dgam.z, (1.f - a_g) * dgam.w);
+                const float4 db2 = make_float4((1.f - a_b) * g0.x, (1.f - a_b) * g0.y, (1.f - a_b) * g0.z, (1.f - a_b) * g0.w);
+                st4(dgb2 + p * 2 * g.C + c, dg2);
+                st4(dgb2 + p * 2 * g.C + g.C + c, db2);
+                if (AMAX) gm = dasr_amax4(dasr_amax4(gm, dg2), db2);
                 dag += dgam.x * (g1.x - g2.x) + dgam.y * (g1.y - g2.y) + dgam.z * (g1.z - g2.z) +
                        dgam.w * (g1.w - g2.w);
                 dab += g0.x * (b1.x - b2.x) + g0.y * (b1.y - b2.y) + g0.z * (b1.z - b2.z) + g0.w * (b1.w - b2.w);
@@ -936,6 +962,8 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             if (i + 1 <= n) iteration(i + 1, DEEP ? setB : setA);
         }
     }
+    // (here, where every lane of every wave is still on the same path)
+    if (AMAX) dasr_amax_commit(dgb2_amax, gm);
     // ---- per-channel sums: reduce over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
     float vals[18] = {S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, dbg.x, dbg.y, dbg.z, dbg.w,
                       dbb.x, dbb.y, dbb.z, dbb.w, dag, dab};
@@ -1020,7 +1048,7 @@ template <typename T>
 static int sean_fwd_impl(const T* t, const float* mean, const float* var, const T* gb2, const float* mask,
                          const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_g,
                          const float* bias_b, const float* alpha_g, const float* alpha_b, const T* residual,
-                         T* out, int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
+                         T* out, int relu, int B, int H, int W, int C, int K, float eps, void* stream, float* out_amax = nullptr) {
     DASR_CHECK_PTR(t); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var); DASR_CHECK_PTR(gb2); DASR_CHECK_PTR(mask);
     DASR_CHECK_PTR(D); DASR_CHECK_PTR(bias_g); DASR_CHECK_PTR(bias_b); DASR_CHECK_PTR(alpha_g); DASR_CHECK_PTR(alpha_b);
     DASR_CHECK_PTR(out);
@@ -1039,8 +1067,14 @@ static int sean_fwd_impl(const T* t, const float* mean, const float* var, const 
         const int per = ((tiles / nwg) << 16) | (tiles % nwg);      // (base, rem), see the kernel; rem < nwg <= 768
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
 #define SEAN_FWD_GO(RELU, RES)                                                                                     \
-    DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES, T>), dim3(nwg, slices), dim3(256), lds, stream, g, t,                        \
-                mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, eps, per)
+    do {                                                                                                           \
+        if (sizeof(T) == 4 && out_amax)                                                                            \
+            DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES, T, sizeof(T) == 4>), dim3(nwg, slices), dim3(256), lds, stream, g, t, \
+                        mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, eps, per, out_amax); \
+        else                                                                                                       \
+            DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES, T>), dim3(nwg, slices), dim3(256), lds, stream, g, t,        \
+                        mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, eps, per, (float*)nullptr); \
+    } while (0)
         if (relu) { if (residual) SEAN_FWD_GO(true, true); else SEAN_FWD_GO(true, false); }
         else      { if (residual) SEAN_FWD_GO(false, true); else SEAN_FWD_GO(false, false); }
 #undef SEAN_FWD_GO
@@ -1050,7 +1084,7 @@ static int sean_fwd_impl(const T* t, const float* mean, const float* var, const 
         size_t lds = sizeof(float) * (size_t)(2 * 9 * K * 64 + K * (SEAN_TH + 2) * (SEAN_TW + 2));
         DASR_LAUNCH((k_sean_fwd<T>), dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2, mask, D,
                     bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps,
-                    fast ? onehot_flag : (const int*)nullptr);
+                    fast ? onehot_flag : (const int*)nullptr, sizeof(T) == 4 ? out_amax : (float*)nullptr);
     }
     DASR_RETURN_LAUNCH_STATUS();
 }
@@ -1058,9 +1092,9 @@ static int sean_fwd_impl(const T* t, const float* mean, const float* var, const 
 extern "C" int dasr_sean_fwd(const float* t, const float* mean, const float* var, const float* gb2, const float* mask,
                              const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_g,
                              const float* bias_b, const float* alpha_g, const float* alpha_b, const float* residual,
-                             float* out, int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
+                             float* out, float* out_amax, int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
     return sean_fwd_impl<float>(t, mean, var, gb2, mask, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual,
-                                out, relu, B, H, W, C, K, eps, stream);
+                                out, relu, B, H, W, C, K, eps, stream, out_amax);
 }
 extern "C" int dasr_sean_fwd_bf16(const unsigned short* t, const float* mean, const float* var, const unsigned short* gb2,
                                   const float* mask, const unsigned char* region, const int* onehot_flag, const float* D,
@@ -1108,7 +1142,8 @@ static int sean_bwd_impl(const T* dout, const T* out, const T* t, const float* m
                          const float* D, const float* bias_g, const float* bias_b, const float* alpha_g,
                          const float* alpha_b, T* dt, T* dgb2, float* dD, float* dbias_g, float* dbias_b,
                          float* dalpha_g, float* dalpha_b, T* dres, void* workspace, size_t workspace_bytes,
-                         int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
+                         int relu, int B, int H, int W, int C, int K, float eps, void* stream, float* dt_amax = nullptr,
+                         float* dgb2_amax = nullptr) {
     DASR_CHECK_PTR(dout); DASR_CHECK_PTR(out); DASR_CHECK_PTR(t); DASR_CHECK_PTR(mean); DASR_CHECK_PTR(var);
     DASR_CHECK_PTR(gb2); DASR_CHECK_PTR(mask); DASR_CHECK_PTR(D); DASR_CHECK_PTR(bias_g); DASR_CHECK_PTR(bias_b);
     DASR_CHECK_PTR(alpha_g); DASR_CHECK_PTR(alpha_b); DASR_CHECK_PTR(dt); DASR_CHECK_PTR(dgb2); DASR_CHECK_PTR(dD);
@@ -1147,14 +1182,23 @@ static int sean_bwd_impl(const T* dout, const T* out, const T* t, const float* m
         int ntiles = ((W + SF_TW - 1) / SF_TW) * ((H + TH - 1) / TH);
         size_t lds = (size_t)sean_bwd_lds_bytes(K, TH, NP);
         if (lds > 160 * 1024) return DASR_E_UNSUPPORTED;
-        if (big)
+        constexpr bool F32 = sizeof(T) == 4;
+        if (F32 && dgb2_amax && big)
+            DASR_LAUNCH((k_sean_bwd_a_onehot<T, TH_BIG, F32>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
+                        mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
+                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles, dgb2_amax);
+        else if (F32 && dgb2_amax)
+            DASR_LAUNCH((k_sean_bwd_a_onehot<T, TH_SMALL, F32>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
+                        mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
+                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles, dgb2_amax);
+        else if (big)
             DASR_LAUNCH((k_sean_bwd_a_onehot<T, TH_BIG>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
                         mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
-                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
+                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles, (float*)nullptr);
         else
             DASR_LAUNCH((k_sean_bwd_a_onehot<T, TH_SMALL>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
                         mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
-                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles);
+                        dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles, (float*)nullptr);
         size_t n = (size_t)B * 18 * K * C;
         DASR_LAUNCH(k_sean_dD_reduce, dim3(dasr_ew_grid(n)), dim3(256), 0, stream, (const float*)slabs, onehot_flag, dD,
                     18 * K * C, nblk, n);
@@ -1164,17 +1208,18 @@ static int sean_bwd_impl(const T* dout, const T* out, const T* t, const float* m
         size_t lds = sean_bwd_general_lds(K);
         DASR_LAUNCH((k_sean_bwd_a<T>), dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, dout, out, t, mean, var,
                     gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, dD, dbias_g, dbias_b, dalpha_g, dalpha_b,
-                    dres, S, relu, eps, fast ? onehot_flag : (const int*)nullptr);
+                    dres, S, relu, eps, fast ? onehot_flag : (const int*)nullptr, sizeof(T) == 4 ? dgb2_amax : (float*)nullptr);
     }
     size_t n = (size_t)B * H * W * C;
     if ((C & 3) == 0 && (256 % (C / 4)) == 0 && B <= 65535) {
         const int npl = 256 / (C / 4);
         unsigned gx = dasr_cdiv((size_t)H * W, npl * 8);     // eight pixels per thread
         if (gx < 1) gx = 1;
-        DASR_LAUNCH((k_sean_bwd_b_rows<T>), dim3(gx, B), dim3(256), 0, stream, t, mean, var, S, dt, H * W, C, eps);
+        DASR_LAUNCH((k_sean_bwd_b_rows<T>), dim3(gx, B), dim3(256), 0, stream, t, mean, var, S, dt, H * W, C, eps,
+                    sizeof(T) == 4 ? dt_amax : (float*)nullptr);
     } else {
         DASR_LAUNCH((k_sean_bwd_b<T>), dim3(dasr_ew_grid((C & 3) == 0 ? n / 4 : n)), dim3(256), 0, stream, t, mean, var, S,
-                    dt, H * W, C, n, eps);
+                    dt, H * W, C, n, eps, sizeof(T) == 4 ? dt_amax : (float*)nullptr);
     }
     DASR_RETURN_LAUNCH_STATUS();
 }
@@ -1183,11 +1228,12 @@ extern "C" int dasr_sean_bwd(const float* dout, const float* out, const float* t
                              const float* gb2, const float* mask, const unsigned char* region, const int* onehot_flag,
                              const float* D, const float* bias_g, const float* bias_b, const float* alpha_g,
                              const float* alpha_b, float* dt, float* dgb2, float* dD, float* dbias_g, float* dbias_b,
-                             float* dalpha_g, float* dalpha_b, float* dres, void* workspace, size_t workspace_bytes,
+                             float* dalpha_g, float* dalpha_b, float* dres, float* dt_amax, float* dgb2_amax,
+                             void* workspace, size_t workspace_bytes,
                              int relu, int B, int H, int W, int C, int K, float eps, void* stream) {
     return sean_bwd_impl<float>(dout, out, t, mean, var, gb2, mask, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b,
                                 dt, dgb2, dD, dbias_g, dbias_b, dalpha_g, dalpha_b, dres, workspace, workspace_bytes, relu, B,
-                                H, W, C, K, eps, stream);
+                                H, W, C, K, eps, stream, dt_amax, dgb2_amax);
 }
 extern "C" int dasr_sean_bwd_bf16(const unsigned short* dout, const unsigned short* out, const unsigned short* t,
                                   const float* mean, const float* var, const unsigned short* gb2, const float* mask,

@@ -40,6 +40,9 @@ SPLIT_WGRAD = True              # ... and their weight gradients (K = pixels: op
 # 3: three bf16 pieces, six products.  2: two fp16 pieces, three products, every tensor operand scaled by a power of two taken
 # from its max |.| (ops.absmax, device side): half the matrix work and measurably closer to float64 (csrc/conv_split_bf16.hip).
 SPLIT_PIECES = 2
+# ... and the kernels that PRODUCE those tensors (SEAN forward / backward, the mask layer, the split kernels' own epilogue, the
+# activation / PixelShuffle backward) leave max |.| behind themselves; False: one ops.absmax pass per operand (A/B, tests)
+FUSE_AMAX = True
 SPLIT_MIN_PIXELS = 1 << 14      # below this the launch is latency-bound either way
 WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
@@ -157,12 +160,34 @@ def bias_pair(tape, ba, bb):
 
 
 def _amax(var):
-    """max |var.data| on the device (ops.absmax), computed once per tensor and stream: the forward convolution and its weight
-    gradient share it."""
+    """max |var.data| on the device for the fp16 x 2 split kernels: what the producing kernel left with the tensor
+    (ops.set_amax: valid wherever the tensor is), else one ops.absmax pass, kept per tensor and stream (the forward
+    convolution and its weight gradient share it)."""
+    a = ops.get_amax(var.data)
+    if a is not None:
+        return a
     key = torch.cuda.current_stream().cuda_stream if var.data.is_cuda else 0
     if var.amax is None or var.amax[0] != key:
         var.amax = (key, ops.absmax(var.data))
     return var.amax[1]
+
+
+def _amax_t(t):
+    """The same for a bare tensor (a gradient on its way through the tape)."""
+    a = ops.get_amax(t)
+    return a if a is not None else ops.absmax(t)
+
+
+def want_amax(tape, like, shape=None):
+    """A zeroed slot for a producer kernel to raise (Tape.amax_slot) when the tensor it is about to write - shaped ``shape``
+    (default: like ``like``), on ``like``'s device - can be the operand of an fp16 x 2 split convolution, else None: NHWC
+    fp32 on the fp32 path, at least SPLIT_MIN_PIXELS pixels."""
+    if not (SPLIT_BF16 and SPLIT_PIECES == 2 and FUSE_AMAX) or like.dtype != torch.float32 or tape.act_dtype != torch.float32:
+        return None
+    shape = tuple(like.shape) if shape is None else shape
+    if len(shape) != 4 or shape[0] * shape[1] * shape[2] < SPLIT_MIN_PIXELS:
+        return None
+    return tape.amax_slot(like)
 
 
 def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.ACT_NONE, ps_r=1, residual=None,
@@ -185,13 +210,18 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
                               (lambda: ops.conv3x3_split_weights(w.data)))
         if isinstance(w.split, tuple):
             y = ops.conv3x3_fwd_split2(x.data, _amax(x), w.split, bias.data if bias is not None else None, w.data.shape[4],
-                                       residual.data if residual is not None else None, act, ps_r)
+                                       residual.data if residual is not None else None, act, ps_r,
+                                       amax=want_amax(tape, x.data))
         else:
             y = ops.conv3x3_fwd_split(x.data, w.split, bias.data if bias is not None else None, w.data.shape[4],
                                       residual.data if residual is not None else None, act, ps_r)
     else:
+        # (the mask layer 1 -> 2C feeds the gamma_o|beta_o convolution, the encoder's first layer the head: their kernel
+        # leaves max |y| behind)
+        am = want_amax(tape, x.data) if (f32 and x.data.shape[3] in (1, 3) and ps_r == 1) else None
         y = ops.conv2d_fwd(x.data, w.data, bias.data if bias is not None else None,
-                           residual.data if residual is not None else None, stride, pad, transposed, act, ps_r, out_dtype)
+                           residual.data if residual is not None else None, stride, pad, transposed, act, ps_r, out_dtype,
+                           amax=am)
     needs = x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad) or \
         (residual is not None and residual.requires_grad)
     out = Var(y, needs)
@@ -225,7 +255,8 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
         if out.grad_is_preact:
             dconv = dy                       # the (single) consumer's dgrad already applied this epilogue's backward
         elif act != ops.ACT_NONE or ps_r > 1:
-            dconv = ops.conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r)
+            dconv = ops.conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r,
+                                            amax=want_amax(tape, dy, (B, Ho, Wo, Cout)) if isinstance(w.split, tuple) else None)
         else:
             dconv = dy
         dmax = None                          # (fp16 x 2 scheme) max |dconv|, shared by the weight and the data gradient
@@ -235,7 +266,7 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
                 ws = _side_stream(dconv.device)       # the depth-branch stream: idle while the HR tail runs backward
             if ws is None and w.split is not None and SPLIT_WGRAD:
                 if isinstance(w.split, tuple):
-                    dmax = ops.absmax(dconv)
+                    dmax = _amax_t(dconv)
                     dw, db = ops.conv3x3_wgrad_split2(x.data, _amax(x), dconv, dmax, want_bias=bias is not None)
                 else:
                     dw, db = ops.conv3x3_wgrad_split(x.data, dconv, want_bias=bias is not None)
@@ -268,7 +299,7 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
                 x.grad_is_preact = True
             elif isinstance(w.split, tuple):
                 if dmax is None:
-                    dmax = ops.absmax(dconv)
+                    dmax = _amax_t(dconv)
                 x.grad = ops.conv3x3_dgrad_split2(dconv, dmax, w.split, x.data.shape, out=x.grad)
             elif w.split is not None:
                 if x.grad is None:
@@ -458,7 +489,8 @@ def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, 
         gb2.data.record_stream(torch.cuda.current_stream())
     mean, var = t.stats if t.stats is not None else ops.instnorm_stats(t.data)
     y = ops.sean_fwd(t.data, mean, var, gb2.data, mask.planes, mask.region, mask.flag, D.data, bias_g.data, bias_b.data,
-                     alpha_g.data, alpha_b.data, residual.data if residual is not None else None, relu)
+                     alpha_g.data, alpha_b.data, residual.data if residual is not None else None, relu,
+                     amax=want_amax(tape, t.data))
     out = Var(y, True)
 
     def bwd():
@@ -467,7 +499,8 @@ def sean_mod(tape, t, gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, residual, 
         want_dres = residual is not None and residual.requires_grad
         dt, dgb2, dD, dbg, dbb, dag, dab, dres = ops.sean_bwd(
             out.grad, y, t.data, mean, var, gb2.data, mask.planes, mask.region, mask.flag, D.data, bias_g.data,
-            bias_b.data, alpha_g.data, alpha_b.data, relu, want_dres)
+            bias_b.data, alpha_g.data, alpha_b.data, relu, want_dres,
+            dt_amax=want_amax(tape, t.data), dgb2_amax=want_amax(tape, gb2.data))
         out.grad = None
         accum(t, dt)
         accum(gb2, dgb2)

@@ -92,6 +92,24 @@ def resize_nearest_u8(region, H, W):
     return out
 
 
+# ---- max |.| of a tensor, carried on the tensor (fp16 x 2 split convolutions) ---------------------------------------
+# A producer kernel that was handed a zeroed device float raises it to the max |.| of what it stores (dasr.h, *_amax
+# arguments); the float then travels with the tensor as an attribute.  Every op that writes into an existing tensor drops it.
+def set_amax(t, amax):
+    if amax is not None:
+        t._dasr_amax = amax
+    return t
+
+
+def get_amax(t):
+    return getattr(t, "_dasr_amax", None)
+
+
+def drop_amax(t):
+    if t is not None and getattr(t, "_dasr_amax", None) is not None:
+        t._dasr_amax = None
+
+
 def add(a, b):
     out = torch.empty_like(a)
     if _is_bf(a, b):
@@ -103,6 +121,7 @@ def add(a, b):
 
 def accumulate_(dst, src):
     assert dst.shape == src.shape
+    drop_amax(dst)
     if dst.dtype == torch.float32 and src.dtype == BF16:       # bf16 gradient arriving at an fp32 tensor
         _call("dasr_cast_bf16_to_f32", _pa(src), _p(dst), 1, dst.numel())
     elif _is_bf(dst, src):
@@ -114,6 +133,7 @@ def accumulate_(dst, src):
 
 def copy_(dst, src):
     assert dst.numel() == src.numel() and dst.dtype == src.dtype
+    drop_amax(dst)
     if dst.dtype == BF16:
         assert dst.numel() % 2 == 0
         _call("dasr_copy", _pa(dst), _pa(src), dst.numel() // 2)      # a byte copy: two bf16 per float
@@ -173,6 +193,7 @@ def depth_to_space2_bwd(dy, x_shape, dtype, out=None, valid_hw=None):
     acc = out is not None
     if out is None:
         out = torch.empty(tuple(x_shape), dtype=dtype, device=dy.device)
+    drop_amax(out)
     _call("dasr_depth_to_space2_bwd_bf16", _pa(dy), _pa(out), 1 if out.dtype == BF16 else 0, 1 if acc else 0, B, H, W, C,
           Hv, Wv)
     return out
@@ -271,9 +292,11 @@ def _wdims(w):
     return tuple(w.shape[1:])
 
 
-def conv2d_fwd(x, w, bias=None, residual=None, stride=1, pad=1, transposed=False, act=ACT_NONE, ps_r=1, out_dtype=None):
+def conv2d_fwd(x, w, bias=None, residual=None, stride=1, pad=1, transposed=False, act=ACT_NONE, ps_r=1, out_dtype=None,
+               amax=None):
     """``out_dtype=torch.bfloat16`` with an fp32 ``x`` is the mask layer of the bf16 path (fp32 depth map in, bf16
-    activation out); a bf16 ``x`` selects the bf16 path by itself (the 9x9 output conv then returns fp32)."""
+    activation out); a bf16 ``x`` selects the bf16 path by itself (the 9x9 output conv then returns fp32).
+    ``amax`` (fp32 path): a zeroed device float that receives max |y| and is attached to y (set_amax)."""
     B, H, W, Cin = x.shape
     KH, KW, wi, Cout = _wdims(w)
     assert wi == Cin, (w.shape, x.shape)
@@ -290,18 +313,20 @@ def conv2d_fwd(x, w, bias=None, residual=None, stride=1, pad=1, transposed=False
         _call("dasr_conv2d_fwd_bf16", _pa(x), _pa(w), _p(bias, True), _pa(residual, True), _pa(y), B, H, W, Cin, Ho, Wo,
               Cout, KH, KW, stride, pad, int(transposed), act, ps_r)
     else:
-        _call("dasr_conv2d_fwd", _p(x), _p(w), _p(bias, True), _p(residual, True), _p(y), B, H, W, Cin, Ho, Wo, Cout, KH,
-              KW, stride, pad, int(transposed), act, ps_r)
+        _call("dasr_conv2d_fwd", _p(x), _p(w), _p(bias, True), _p(residual, True), _p(y), _p(amax, True), B, H, W, Cin, Ho, Wo,
+              Cout, KH, KW, stride, pad, int(transposed), act, ps_r)
+        set_amax(y, amax)
     return y
 
 
-def conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r):
+def conv2d_epilogue_bwd(dy, y, Ho, Wo, Cout, act, ps_r, amax=None):
     B = y.shape[0]
     dconv = empty((B, Ho, Wo, Cout), y, y.dtype)
     if _is_bf(dy, y):
         _call("dasr_conv2d_epilogue_bwd_bf16", _pa(dy), _pa(y), _pa(dconv), B, Ho, Wo, Cout, act, ps_r)
     else:
-        _call("dasr_conv2d_epilogue_bwd", _p(dy), _p(y), _p(dconv), B, Ho, Wo, Cout, act, ps_r)
+        _call("dasr_conv2d_epilogue_bwd", _p(dy), _p(y), _p(dconv), _p(amax, True), B, Ho, Wo, Cout, act, ps_r)
+        set_amax(dconv, amax)
     return dconv
 
 
@@ -313,6 +338,7 @@ def conv2d_dgrad(dconv, w, x_shape, stride=1, pad=1, transposed=False, out=None,
     acc = out is not None
     if out is None:
         out = torch.empty(x_shape, dtype=out_dtype, device=dconv.device)
+    drop_amax(out)
     if out.dtype == BF16:
         _call("dasr_conv2d_dgrad_bf16", _pa(dconv), _pa(w), _pa(out), int(acc), B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride,
               pad, int(transposed))
@@ -427,6 +453,7 @@ def conv3x3_dgrad_split(dconv, ws, x_shape, out=None):
     acc = out is not None
     if out is None:
         out = empty(tuple(x_shape), dconv)
+    drop_amax(out)
     _call("dasr_conv3x3_dgrad_split", _p(dconv), _pa(ws), _p(out), 1 if acc else 0, B, H, W, Cin, Cout)
     return out
 
@@ -451,15 +478,15 @@ def conv3x3_split2_weights(w):
     return ws, wmax
 
 
-def conv3x3_fwd_split2(x, xmax, ws, bias, Cout, residual=None, act=ACT_NONE, ps_r=1):
+def conv3x3_fwd_split2(x, xmax, ws, bias, Cout, residual=None, act=ACT_NONE, ps_r=1, amax=None):
     B, H, W, Cin = x.shape
     if ps_r > 1:
         y = empty((B, H * ps_r, W * ps_r, Cout // (ps_r * ps_r)), x)
     else:
         y = empty((B, H, W, Cout), x)
-    _call("dasr_conv3x3_fwd_split2", _p(x), _p(xmax), _lib.ptr(ws[0], False, torch.float16), _p(ws[1]), _p(bias, True), _p(residual, True), _p(y), B, H, W,
-          Cin, Cout, act, ps_r)
-    return y
+    _call("dasr_conv3x3_fwd_split2", _p(x), _p(xmax), _lib.ptr(ws[0], False, torch.float16), _p(ws[1]), _p(bias, True),
+          _p(residual, True), _p(y), _p(amax, True), B, H, W, Cin, Cout, act, ps_r)
+    return set_amax(y, amax)
 
 
 def conv3x3_wgrad_split2(x, xmax, dconv, dmax, want_bias=True):
@@ -480,6 +507,7 @@ def conv3x3_dgrad_split2(dconv, dmax, ws, x_shape, out=None):
     acc = out is not None
     if out is None:
         out = empty(tuple(x_shape), dconv)
+    drop_amax(out)
     _call("dasr_conv3x3_dgrad_split2", _p(dconv), _p(dmax), _lib.ptr(ws[0], False, torch.float16), _p(ws[1]), _p(out), 1 if acc else 0, B, H, W, Cin, Cout)
     return out
 
@@ -571,19 +599,24 @@ def _rf(region, flag):
     return _lib.ptr(region, dtype=torch.uint8), (_lib.ptr(flag, dtype=torch.int32) if flag is not None else None)
 
 
-def sean_fwd(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu):
+def sean_fwd(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu, amax=None):
     B, H, W, C = t.shape
     K = mask.shape[1]
     assert mask.shape == (B, K, H, W) and gb2.shape == (B, H, W, 2 * C) and D.shape == (B, 2, 9, K, C)
     out = torch.empty_like(t)
     rp, fp = _rf(region, flag)
-    name = "dasr_sean_fwd_bf16" if _is_bf(t, gb2, residual) else "dasr_sean_fwd"
-    _call(name, _pa(t), _p(mean), _p(var), _pa(gb2), _p(mask), rp, fp, _p(D), _p(bias_g), _p(bias_b),
-          _p(alpha_g), _p(alpha_b), _pa(residual, True), _pa(out), int(relu), B, H, W, C, K, IN_EPS)
+    if _is_bf(t, gb2, residual):
+        _call("dasr_sean_fwd_bf16", _pa(t), _p(mean), _p(var), _pa(gb2), _p(mask), rp, fp, _p(D), _p(bias_g), _p(bias_b),
+              _p(alpha_g), _p(alpha_b), _pa(residual, True), _pa(out), int(relu), B, H, W, C, K, IN_EPS)
+    else:
+        _call("dasr_sean_fwd", _p(t), _p(mean), _p(var), _p(gb2), _p(mask), rp, fp, _p(D), _p(bias_g), _p(bias_b),
+              _p(alpha_g), _p(alpha_b), _p(residual, True), _p(out), _p(amax, True), int(relu), B, H, W, C, K, IN_EPS)
+        set_amax(out, amax)
     return out
 
 
-def sean_bwd(dout, out, t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, relu, want_dres):
+def sean_bwd(dout, out, t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, relu, want_dres,
+             dt_amax=None, dgb2_amax=None):
     B, H, W, C = t.shape
     K = mask.shape[1]
     lib = _lib.get()
@@ -596,10 +629,16 @@ def sean_bwd(dout, out, t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b
     dag, dab = empty((1,), t), empty((1,), t)
     dres = torch.empty_like(t) if want_dres else None
     rp, fp = _rf(region, flag)
-    name = "dasr_sean_bwd_bf16" if _is_bf(dout, out, t, gb2) else "dasr_sean_bwd"
-    _call(name, _pa(dout), _pa(out), _pa(t), _p(mean), _p(var), _pa(gb2), _p(mask), rp, fp, _p(D), _p(bias_g),
-          _p(bias_b), _p(alpha_g), _p(alpha_b), _pa(dt), _pa(dgb2), _p(dD), _p(dbg), _p(dbb), _p(dag), _p(dab),
-          _pa(dres, True), _p(ws), nbytes, int(relu), B, H, W, C, K, IN_EPS)
+    if _is_bf(dout, out, t, gb2):
+        _call("dasr_sean_bwd_bf16", _pa(dout), _pa(out), _pa(t), _p(mean), _p(var), _pa(gb2), _p(mask), rp, fp, _p(D), _p(bias_g),
+              _p(bias_b), _p(alpha_g), _p(alpha_b), _pa(dt), _pa(dgb2), _p(dD), _p(dbg), _p(dbb), _p(dag), _p(dab),
+              _pa(dres, True), _p(ws), nbytes, int(relu), B, H, W, C, K, IN_EPS)
+    else:
+        _call("dasr_sean_bwd", _p(dout), _p(out), _p(t), _p(mean), _p(var), _p(gb2), _p(mask), rp, fp, _p(D), _p(bias_g),
+              _p(bias_b), _p(alpha_g), _p(alpha_b), _p(dt), _p(dgb2), _p(dD), _p(dbg), _p(dbb), _p(dag), _p(dab),
+              _p(dres, True), _p(dt_amax, True), _p(dgb2_amax, True), _p(ws), nbytes, int(relu), B, H, W, C, K, IN_EPS)
+        set_amax(dt, dt_amax)
+        set_amax(dgb2, dgb2_amax)
     return dt, dgb2, dD, dbg, dbb, dag, dab, dres
 
 

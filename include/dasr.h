@@ -91,9 +91,11 @@ int dasr_weight_pack_bwd(const float* dw_hwio, const float* v, const float* g, c
  *   ps_r > 1 writes y as [B][Ho*r][Wo*r][Cout/r^2] with
  *   y[b, oy*r+i, ox*r+j, c] = act(conv[b,oy,ox, c*r*r + i*r + j])   (bit-exact index map of nn.PixelShuffle).
  * bias, residual may be NULL.
+ * y_amax (may be NULL): max |y| for a following fp16 x 2 split convolution - zero on entry, raised atomically (by the mask
+ * layer's kernel while it stores; by a pass over y after every other kernel).  See dasr_absmax.
  */
-int dasr_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, const float* residual, float* y, int B,
-                    int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+int dasr_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, const float* residual, float* y, float* y_amax,
+                    int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                     int transposed, int act, int ps_r, void* stream);
 /* dasr_conv2d_fwd for a 3x3 / stride 1 / pad 1 convolution with bias and no activation, PLUS the statistics
  * nn.InstanceNorm2d(affine=False) needs of its output (sftmd_arch.py:811-820: `conv1 = Sequential(Conv2d, InstanceNorm2d)`):
@@ -105,9 +107,10 @@ size_t dasr_conv2d_fwd_stats_workspace(int B, int H, int W, int Cin, int Cout);
 int dasr_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* mean, float* var,
                           void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
 
-/* Backward of the epilogue: dconv[b,oy,ox,cc] = dy[...shuffled...] * act'(y[...]) (y = saved forward output). */
-int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, int B, int Ho, int Wo, int Cout, int act,
-                             int ps_r, void* stream);
+/* Backward of the epilogue: dconv[b,oy,ox,cc] = dy[...shuffled...] * act'(y[...]) (y = saved forward output).
+ * dconv_amax (may be NULL): max |dconv|, zero on entry, raised atomically by the kernel (see dasr_absmax). */
+int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, float* dconv_amax, int B, int Ho, int Wo,
+                             int Cout, int act, int ps_r, void* stream);
 /* dx (+)= conv-transpose of dconv with w; accumulate != 0 adds into dx. */
 int dasr_conv2d_dgrad(const float* dconv, const float* w_hwio, float* dx, int accumulate, int B, int H, int W, int Cin,
                       int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int transposed, void* stream);
@@ -173,15 +176,17 @@ int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, float* dw_hwio,
  *   dasr_absmax:     *amax = max |x| over n floats (x 16-byte aligned); cleared and written on the stream (device memory:
  *                    the kernels below derive the scale from its exponent bits, nothing is read back by the host)
  *   split2_weights:  wmax = dasr_absmax of the packed kernel's plane 0 (9 Cin Cout floats); image: split2_weights_bytes
- *   fwd / dgrad / wgrad_split2: as the functions above plus the maxima of their tensor operands (xmax of x, dmax of dconv)
+ *   fwd / dgrad / wgrad_split2: as the functions above plus the maxima of their tensor operands (xmax of x, dmax of dconv);
+ *                    y_amax (may be NULL): max |y| of what the forward stores, for the NEXT split convolution - zero on
+ *                    entry, raised atomically from the epilogue (the contract of every *_amax argument of this header)
  * Same nn.Conv2d calls replaced (normalization.py:41-42,73-74; sftmd_arch.py:811-820 and the upscale tail :891-909). */
 int dasr_absmax(const float* x, size_t n, float* amax, void* stream);
 size_t dasr_conv3x3_split2_weights_bytes(int Cin, int Cout);
 int dasr_conv3x3_split2_weights(const float* w_packed, const float* wmax, unsigned short* w_split, int Cin, int Cout,
                                 void* stream);
 int dasr_conv3x3_fwd_split2(const float* x, const float* xmax, const unsigned short* w_split, const float* wmax,
-                            const float* bias, const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
-                            int act, int ps_r, void* stream);
+                            const float* bias, const float* residual, float* y, float* y_amax, int B, int H, int W, int Cin,
+                            int Cout, int act, int ps_r, void* stream);
 int dasr_conv3x3_dgrad_split2(const float* dconv, const float* dmax, const unsigned short* w_split, const float* wmax,
                               float* dx, int accumulate, int B, int H, int W, int Cin, int Cout, void* stream);
 int dasr_conv3x3_wgrad_split2(const float* x, const float* xmax, const float* dconv, const float* dmax, float* dw_hwio,
@@ -238,19 +243,22 @@ int dasr_mask_compress(const float* mask, unsigned char* region, int* onehot_fla
                        void* stream);
 int dasr_sean_fwd(const float* t, const float* mean, const float* var, const float* gb2, const float* mask,
                   const unsigned char* region, const int* onehot_flag, const float* D, const float* bias_gamma, const float* bias_beta, const float* alpha_gamma,
-                  const float* alpha_beta, const float* residual, float* out, int relu, int B, int H, int W, int C,
-                  int K, float eps, void* stream);
+                  const float* alpha_beta, const float* residual, float* out, float* out_amax, int relu, int B, int H,
+                  int W, int C, int K, float eps, void* stream);
 /* Backward. Inputs as forward plus dout and the saved forward output `out` (for the ReLU mask).
  * Outputs: dt [B,H,W,C]; dgb2 [B,H,W,2C]; dD [B,2,9,K,C]; dbias_gamma, dbias_beta [C]; dalpha_gamma, dalpha_beta [1];
- * dres (may be NULL; written = dout*relu') ; workspace: dasr_sean_bwd_workspace() bytes. */
+ * dres (may be NULL; written = dout*relu') ; workspace: dasr_sean_bwd_workspace() bytes.
+ * out_amax / dt_amax / dgb2_amax (fp32 entry points, each may be NULL): max |.| of the tensor just written, for the
+ * fp16 x 2 split convolution that reads it next - ZERO (or a lower bound) on entry, raised atomically by the producing
+ * kernel itself (no extra pass over the tensor; see dasr_absmax). */
 size_t dasr_sean_bwd_workspace(int B, int H, int W, int C, int K);
 int dasr_sean_bwd(const float* dout, const float* out, const float* t, const float* mean, const float* var,
                   const float* gb2, const float* mask, const unsigned char* region, const int* onehot_flag,
                   const float* D, const float* bias_gamma, const float* bias_beta,
                   const float* alpha_gamma, const float* alpha_beta, float* dt, float* dgb2, float* dD,
                   float* dbias_gamma, float* dbias_beta, float* dalpha_gamma, float* dalpha_beta, float* dres,
-                  void* workspace, size_t workspace_bytes, int relu, int B, int H, int W, int C, int K, float eps,
-                  void* stream);
+                  float* dt_amax, float* dgb2_amax, void* workspace, size_t workspace_bytes, int relu, int B, int H, int W,
+                  int C, int K, float eps, void* stream);
 
 /* Largest K for which the soft-mask (general) kernels run forward and backward (their backward keeps two
  * [2][9][K][64] tables in LDS).  With more regions (up to 16) only one-hot masks are supported: pass region bytes with

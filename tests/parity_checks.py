@@ -1139,6 +1139,120 @@ def check_absmax(device, seed=3):
     return dict(ok=True)
 
 
+def check_fused_amax(device, seed=11):
+    """Every producer kernel that leaves max |.| of what it stores behind (the *_amax arguments of dasr.h) against torch's
+    abs().max() of the tensor it wrote - EXACT (the kernels take maxima of the stored values themselves): SEAN forward
+    (one-hot and soft masks, with / without ReLU and residual), SEAN backward (dt, dgb2), the mask layer, a convolution
+    whose kernel does not track it (follow-up pass inside the entry point), the activation / PixelShuffle backward in its
+    three forms, the fp16 x 2 split forward (plain, residual + ReLU, PixelShuffle(2), the 32-channel tile)."""
+    gen = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    dev = lambda t: t.to(device)
+    z = lambda: torch.zeros(1).to(device)
+    amx = lambda t: t.detach().abs().max().item()
+    out = {}
+    # ---- SEAN
+    B, H, W, C, K = 2, 9, 37, 64, 10
+    t, gb2, res = rn(B, H, W, C), rn(B, H, W, 2 * C), rn(B, H, W, C) * 3.0
+    _, _, _, mk = synth.closed_form_batch(1, B, H, W, 1, K)
+    D = rn(B, 2, 9, K, C) * 0.1
+    bg, bb = rn(C) * 0.1, rn(C) * 0.1
+    ag, ab = torch.full((1,), 0.7), torch.full((1,), 0.74)
+    dout = rn(B, H, W, C) * 1e-5
+    mean, var = ops.instnorm_stats(dev(t))
+    for soft in (False, True):
+        mask = dev(mk if not soft else (0.7 * mk + 0.3 * torch.rand(mk.shape, generator=gen)))
+        region, flag = ops.mask_compress(mask)
+        for relu, r in ((True, None), (False, None), (True, res), (False, res)):
+            a = z()
+            y = ops.sean_fwd(dev(t), mean, var, dev(gb2), mask, region, flag, dev(D), dev(bg), dev(bb), dev(ag), dev(ab),
+                             dev(r) if r is not None else None, relu, amax=a)
+            assert ops.get_amax(y) is a and a.item() == amx(y), ("sean fwd", soft, relu, r is not None, a.item(), amx(y))
+            y0 = ops.sean_fwd(dev(t), mean, var, dev(gb2), mask, region, flag, dev(D), dev(bg), dev(bb), dev(ag), dev(ab),
+                              dev(r) if r is not None else None, relu)
+            assert torch.equal(y, y0) and ops.get_amax(y0) is None
+            a1, a2 = z(), z()
+            rr = ops.sean_bwd(dev(dout), y, dev(t), mean, var, dev(gb2), mask, region, flag, dev(D), dev(bg), dev(bb), dev(ag),
+                              dev(ab), relu, r is not None, dt_amax=a1, dgb2_amax=a2)
+            assert a1.item() == amx(rr[0]) and a2.item() == amx(rr[1]), ("sean bwd", soft, relu, a1.item(), amx(rr[0]), a2.item(), amx(rr[1]))
+            assert a1.item() > 0 and a2.item() > 0
+    out["sean"] = True
+    # ---- the mask layer (kernel tracks it) and a 3 -> 32 layer on the same entry point, a 3x3 MFMA convolution (follow-up pass)
+    for (cin, cout, act) in ((1, 128, ops.ACT_RELU), (3, 32, ops.ACT_LRELU), (32, 64, ops.ACT_NONE)):
+        x = rn(2, 11, 37, cin)
+        w = ops.pack_hwio(dev(rn(3, 3, cin, cout) * 0.3))
+        b = dev(rn(cout))
+        a = z()
+        y = ops.conv2d_fwd(dev(x), w, b, act=act, amax=a)
+        assert a.item() == amx(y), ("conv fwd amax", cin, cout, a.item(), amx(y))
+        assert torch.equal(y, ops.conv2d_fwd(dev(x), w, b, act=act))
+    # ---- activation / PixelShuffle backward
+    for (Cq, act, ps, Hs, Ws) in ((8, 1, 1, 6, 5), (8, 2, 2, 6, 5), (4, 2, 3, 5, 7), (3, 2, 1, 5, 7)):
+        yv, dyv = rn(2, Hs * ps, Ws * ps, Cq), rn(2, Hs * ps, Ws * ps, Cq) * 1e-4
+        a = z()
+        d = ops.conv2d_epilogue_bwd(dev(dyv), dev(yv), Hs, Ws, Cq * ps * ps, act, ps, amax=a)
+        assert a.item() == amx(d), ("epilogue bwd amax", Cq, act, ps, a.item(), amx(d))
+        assert torch.equal(d, ops.conv2d_epilogue_bwd(dev(dyv), dev(yv), Hs, Ws, Cq * ps * ps, act, ps))
+    # ---- fp16 x 2 split forward
+    for (cin, cout, act, with_res, ps, Hs, Ws) in ((64, 64, 0, False, 1, 17, 35), (32, 128, 1, True, 1, 9, 33), (32, 128, 2, False, 2, 9, 33),
+                                                    (64, 32, 2, False, 1, 9, 40)):
+        x = rn(1, Hs, Ws, cin) * 5.0
+        wp = ops.pack_hwio(dev(rn(3, 3, cin, cout) * (1.0 / math.sqrt(9 * cin))))
+        ws = ops.conv3x3_split2_weights(wp)
+        b = dev(rn(cout))
+        r = dev(rn(1, Hs, Ws, cout)) if with_res else None
+        xm = ops.absmax(dev(x))
+        a = z()
+        y = ops.conv3x3_fwd_split2(dev(x), xm, ws, b, cout, r, act, ps, amax=a)
+        assert a.item() == amx(y), ("split fwd amax", cin, cout, act, ps, a.item(), amx(y))
+        assert torch.equal(y, ops.conv3x3_fwd_split2(dev(x), xm, ws, b, cout, r, act, ps))
+    # ---- an in-place writer drops what the tensor carried
+    y = ops.conv2d_fwd(dev(rn(1, 5, 5, 1)), ops.pack_hwio(dev(rn(3, 3, 1, 8))), None, amax=z())
+    assert ops.get_amax(y) is not None
+    ops.accumulate_(y, y.clone())
+    assert ops.get_amax(y) is None
+    return out
+
+
+def check_fused_amax_net(device, case_name="x8_nb4"):
+    """Whole net with the fp16 x 2 split convolutions forced on: the maxima left behind by the producing kernels
+    (graph.FUSE_AMAX) against one dasr_absmax pass per operand - the same scales, so output and every gradient BIT-identical;
+    and the fused run must launch far fewer absmax passes."""
+    from dasr_amd import graph
+    case = [c for c in DEPTHNET_CASES if c["name"] == case_name][0]
+    net, cfg = build_net(case, device)
+    lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, case["B"], case["H"], case["W"], cfg["scale"])]
+    old = graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.FUSE_AMAX
+    calls = {}
+    orig_absmax = ops.absmax
+    res = {}
+    try:
+        graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES = 0, 2
+        for fused in (True, False):
+            graph.FUSE_AMAX = fused
+            n = [0]
+
+            def counted(x, _n=n):
+                _n[0] += 1
+                return orig_absmax(x)
+
+            ops.absmax = counted
+            net.zero_grad(set_to_none=True)
+            sr = net(lq, dm, mk)
+            wgt = torch.cos(torch.arange(sr.numel(), dtype=torch.float32) * 0.013).reshape(sr.shape).to(device)
+            (sr * wgt).sum().backward()
+            res[fused] = (sr.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+            calls[fused] = n[0]
+    finally:
+        ops.absmax = orig_absmax
+        graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.FUSE_AMAX = old
+    assert torch.equal(res[True][0], res[False][0]), "forward differs between fused and separate maxima"
+    for k, gten in res[False][1].items():
+        assert torch.equal(res[True][1][k], gten), ("gradient differs", k)
+    assert calls[True] * 2 <= calls[False], calls          # (what is left: the kernels' own maxima, a few unfused producers)
+    return dict(absmax_passes_fused=calls[True], absmax_passes_separate=calls[False])
+
+
 def check_split_conv(device, seed=5, pieces=3):
     """dasr_conv3x3_{fwd,dgrad}_split - fp32 convolutions as six bf16 MFMA products of three-piece operands - against
     torch's FLOAT64 convolution of the same fp32 operands, next to the exact-fp32 MFMA kernels they replace

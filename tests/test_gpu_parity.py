@@ -37,6 +37,14 @@ def test_absmax():
     print(pc.check_absmax("cuda"))
 
 
+def test_fused_amax():
+    print(pc.check_fused_amax("cuda"))
+
+
+def test_fused_amax_net():
+    print(pc.check_fused_amax_net("cuda"))
+
+
 def test_ssim_kernel():
     print(pc.check_ssim_kernel("cuda"))
 

@@ -22,6 +22,14 @@ def test_absmax(emu):
     print(pc.check_absmax("cpu"))
 
 
+def test_fused_amax(emu):
+    print(pc.check_fused_amax("cpu"))
+
+
+def test_fused_amax_net(emu):
+    print(pc.check_fused_amax_net("cpu"))
+
+
 def test_pixel_shuffle_bit_exact(emu):
     pc.check_pixel_shuffle_bit_exact("cpu")
 

@@ -26,12 +26,12 @@ x = torch.randn(B, H, W, Cin, device=dev)
 w = torch.randn(2 * 9 * Cin * Cout, device=dev) * 0.05
 y = torch.empty(B, H, W, Cout, device=dev)
 P = ctypes.c_void_p
-lib.dasr_conv2d_fwd.argtypes = [P, P, P, P, P] + [ctypes.c_int] * 14 + [P]
+lib.dasr_conv2d_fwd.argtypes = [P, P, P, P, P, P] + [ctypes.c_int] * 14 + [P]
 lib.dasr_conv2d_fwd.restype = ctypes.c_int
 
 
 def run():
-    rc = lib.dasr_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, H, W, Cin, H, W, Cout, 3, 3, 1, 1,
+    rc = lib.dasr_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), None, B, H, W, Cin, H, W, Cout, 3, 3, 1, 1,
                              0, 0, 1, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
 
