@@ -122,13 +122,13 @@ class SeanTimer:
     def install(self):
         orig = self._orig
 
-        def timed(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu):
+        def timed(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu, **kw):
             if not self.enabled:
-                return orig(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu)
+                return orig(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu, **kw)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = orig(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu)
+            out = orig(t, mean, var, gb2, mask, region, flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, relu, **kw)
             e1.record()
             B, H, W, C = t.shape
             self.pairs.append((e0, e1, sean_algorithmic_bytes(B, H, W, C, mask.shape[1], residual is not None),

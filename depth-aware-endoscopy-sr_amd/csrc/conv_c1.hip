@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict_
             om = dasr_amax4(om, acc);
         }
     }
-    if (amax) dasr_amax_commit(amax, om);
+    if (amax) dasr_amax_commit(amax, om, sRow, dasr_flat_wg(), dasr_flat_nwg());     // (grid <= 2048 workgroups)
 }
 
 // dw[tap][co] = sum_p x[p+tap] * dconv[p][co], dbias[co] = sum_p dconv[p][co], dconv = dy * act'(y)

@@ -52,6 +52,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_conv_epilogue_bwd(ConvGeom g, const T* __restrict__ dy,
                                                            const T* __restrict__ y, T* __restrict__ dconv,
                                                            int act, int ps_r, float* __restrict__ amax) {
+    __shared__ float s_part[16];
     size_t n = (size_t)g.B * g.Ho * g.Wo * g.Cout;
     float om = 0.f;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(256) k_conv_epilogue_bwd(ConvGeom g, const T* 
         st1(dconv + idx, v);
         om = dasr_amax1(om, v);
     }
-    if (amax) dasr_amax_commit(amax, om);
+    if (amax) dasr_amax_commit(amax, om, s_part, dasr_flat_wg(), dasr_flat_nwg());
 }
 
 // ------------------------------------------------------------------------------------------ dgrad
@@ -194,6 +195,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_conv_epilogue_bwd_flat4(const T* __restrict__ dy, const T* __restrict__ y,
                                                                  T* __restrict__ dconv, size_t n4, int act,
                                                                  float* __restrict__ amax) {
+    __shared__ float s_part[16];
     float om = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 d = ld4(dy + 4 * i), v = ld4(y + 4 * i);
@@ -202,46 +204,59 @@ __global__ void __launch_bounds__(256) k_conv_epilogue_bwd_flat4(const T* __rest
         st4(dconv + 4 * i, o);
         om = dasr_amax4(om, o);
     }
-    if (amax) dasr_amax_commit(amax, om);
+    if (amax) dasr_amax_commit(amax, om, s_part, dasr_flat_wg(), dasr_flat_nwg());
 }
 // PixelShuffle(R): one thread per (conv pixel, shuffled channel c): R*R coalesced 4-byte reads of dy / y (consecutive
 // lanes = consecutive c), one contiguous run of R*R floats written (co = c*R*R + i*R + j).  blockIdx.y = conv row
 // (b*Ho + oy), so the only division left is e / Cq.
 template <int R, typename T>
 __global__ void __launch_bounds__(256) k_conv_epilogue_bwd_ps(const T* __restrict__ dy, const T* __restrict__ y,
-                                                              T* __restrict__ dconv, int Wo, int Cq, int act,
+                                                              T* __restrict__ dconv, int Wo, int Cq, int act, int rows,
                                                               float* __restrict__ amax) {
+    __shared__ float s_part[16];
     const int e0 = blockIdx.x * 256 + threadIdx.x;
-    const bool livee = e0 < Wo * Cq;                                      // (no early return: the wave meets in dasr_amax_commit)
+    const bool livee = e0 < Wo * Cq;                                      // (no early return: the workgroup meets in dasr_amax_commit)
     const int e = livee ? e0 : Wo * Cq - 1;
     const int ox = e / Cq, c = e - ox * Cq;
-    const size_t row = blockIdx.y;                                        // b*Ho + oy
     const size_t srow = (size_t)Wo * R * Cq;                              // floats per shuffled row
-    const T* dyp = dy + row * R * srow + (size_t)ox * R * Cq + c;
-    const T* yp = y + row * R * srow + (size_t)ox * R * Cq + c;
-    float out[R * R];
+    float om = 0.f;
+    // blockIdx.y walks the conv rows (b*Ho + oy) with stride gridDim.y (the grid stays below DASR_AMAX_MAX_PARTS workgroups
+    // when a maximum is wanted), TWO rows per trip: the 2 R*R loads of both are issued before the first store (one row per
+    // trip left a dependent round trip per row: 1385 -> 1541 us on the 32 -> 128 PixelShuffle layer at 512 x 640)
+    for (size_t row0 = blockIdx.y; row0 < (size_t)rows; row0 += 2 * (size_t)gridDim.y) {
+        const size_t row1 = row0 + gridDim.y;
+        const bool two = row1 < (size_t)rows;
+        const size_t rws[2] = {row0, two ? row1 : row0};
+        float out[2][R * R];
 #pragma unroll
-    for (int i = 0; i < R; ++i)
+        for (int h = 0; h < 2; ++h) {
+            const T* dyp = dy + rws[h] * R * srow + (size_t)ox * R * Cq + c;
+            const T* yp = y + rws[h] * R * srow + (size_t)ox * R * Cq + c;
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const size_t o = (size_t)i * srow + (size_t)j * Cq;
-            out[i * R + j] = ld1(dyp + o) * dasr_act_grad_from_out(ld1(yp + o), act);
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const size_t o = (size_t)i * srow + (size_t)j * Cq;
+                    out[h][i * R + j] = ld1(dyp + o) * dasr_act_grad_from_out(ld1(yp + o), act);
+                }
         }
-    T* dst = dconv + (row * Wo + ox) * (size_t)(Cq * R * R) + (size_t)c * (R * R);
-    if (livee) {
-        if (R == 2) {
-            st4(dst, make_float4(out[0], out[1], out[2], out[3]));
-        } else {
 #pragma unroll
-            for (int q = 0; q < R * R; ++q) st1(dst + q, out[q]);
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            T* dst = dconv + (rws[h] * Wo + ox) * (size_t)(Cq * R * R) + (size_t)c * (R * R);
+            if (livee) {
+                if (R == 2) {
+                    st4(dst, make_float4(out[h][0], out[h][1], out[h][2], out[h][3]));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < R * R; ++q) st1(dst + q, out[h][q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < R * R; ++q) om = dasr_amax1(om, out[h][q]);
         }
     }
-    if (amax) {
-        float om = 0.f;
-#pragma unroll
-        for (int q = 0; q < R * R; ++q) om = dasr_amax1(om, out[q]);
-        dasr_amax_commit(amax, om);
-    }
+    if (amax) dasr_amax_commit(amax, om, s_part, dasr_flat_wg(), dasr_flat_nwg());
 }
 
 template <typename T>
@@ -251,14 +266,19 @@ static int conv_epilogue_bwd_impl(const ConvGeom& g, const T* dy, const T* y, T*
     const size_t rows = (size_t)g.B * g.Ho;
     if (ps_r <= 1 && (n % 4) == 0) {
         DASR_LAUNCH((k_conv_epilogue_bwd_flat4<T>), dim3(dasr_ew_grid(n / 4)), dim3(256), 0, stream, dy, y, dconv, n / 4, act, amax);
-    } else if ((ps_r == 2 || ps_r == 3) && (g.Cout % (ps_r * ps_r)) == 0 && rows <= 65535 &&
+    } else if ((ps_r == 2 || ps_r == 3) && (g.Cout % (ps_r * ps_r)) == 0 && rows < ((size_t)1 << 31) &&
                (size_t)g.Wo * (g.Cout / (ps_r * ps_r)) < (1u << 30)) {
         const int Cq = g.Cout / (ps_r * ps_r);
-        const dim3 grid(dasr_cdiv((size_t)g.Wo * Cq, 256), (unsigned)rows);
+        const unsigned gx = dasr_cdiv((size_t)g.Wo * Cq, 256);
+        // one conv row per workgroup up to 65535 rows; with a maximum to leave behind, few enough workgroups for one partial each
+        size_t gy = rows < 65535 ? rows : 65535;
+        if (amax && (size_t)gx * gy > DASR_AMAX_MAX_PARTS) gy = DASR_AMAX_MAX_PARTS / gx > 0 ? DASR_AMAX_MAX_PARTS / gx : 1;
+        if (amax && (size_t)gx * gy > DASR_AMAX_MAX_PARTS) return DASR_E_UNSUPPORTED;
+        const dim3 grid(gx, (unsigned)gy);
         if (ps_r == 2)
-            DASR_LAUNCH((k_conv_epilogue_bwd_ps<2, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act, amax);
+            DASR_LAUNCH((k_conv_epilogue_bwd_ps<2, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act, (int)rows, amax);
         else
-            DASR_LAUNCH((k_conv_epilogue_bwd_ps<3, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act, amax);
+            DASR_LAUNCH((k_conv_epilogue_bwd_ps<3, T>), grid, dim3(256), 0, stream, dy, y, dconv, g.Wo, Cq, act, (int)rows, amax);
     } else {
         DASR_LAUNCH((k_conv_epilogue_bwd<T>), dim3(dasr_ew_grid(n)), dim3(256), 0, stream, g, dy, y, dconv, act, ps_r, amax);
     }

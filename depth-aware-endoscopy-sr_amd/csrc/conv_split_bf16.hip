@@ -149,13 +149,38 @@ template <> struct SpFrag<2> {
         return c;
     }
 };
-// per-launch scale state of the fp16 scheme: the activation scale and the inverse of (activation scale x kernel scale)
+// per-launch scale state of the fp16 scheme: the activation scale and the inverse of (activation scale x kernel scale).
+// The maxima come as amax buffers (dasr_common.h: word 0 = n, then n partial maxima, one per workgroup of the producer): every
+// thread folds a strided share, waves meet through s_red (2 x 16 floats of LDS), and after the workgroup's next barrier
+// sp_scales_take has both maxima.  NP = 3: nothing to do.
 struct SpScale { float sx, inv; };
+__device__ __forceinline__ float sp_amax_share(const float* buf) {
+    int n;
+    memcpy(&n, buf, 4);
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, buf[1 + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
 template <int NP>
-__device__ __forceinline__ SpScale sp_scales(const float* xmax, const float* wmax) {
+__device__ __forceinline__ void sp_scales_gather(const float* xmax, const float* wmax, float* s_red) {
+    if (NP == 2) {
+        const float mx = sp_amax_share(xmax), mw = sp_amax_share(wmax);
+        if ((threadIdx.x & 63) == 0) {
+            s_red[threadIdx.x >> 6] = mx;
+            s_red[16 + (threadIdx.x >> 6)] = mw;
+        }
+    }
+}
+template <int NP>
+__device__ __forceinline__ SpScale sp_scales_take(const float* s_red) {
     SpScale r = {1.f, 1.f};
     if (NP == 2) {
-        const int kx = sp_scale_exp(*xmax), kw = sp_scale_exp(*wmax);
+        const int nw = (int)(blockDim.x >> 6);
+        float mx = s_red[0], mw = s_red[16];
+        for (int w = 1; w < nw; ++w) { mx = fmaxf(mx, s_red[w]); mw = fmaxf(mw, s_red[16 + w]); }
+        const int kx = sp_scale_exp(mx), kw = sp_scale_exp(mw);
         r.sx = sp_pow2(kx);
         r.inv = sp_pow2(-(kx + kw));
     }
@@ -260,26 +285,31 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     constexpr int R = 3, D = 2;
     char* const sW = smem + 2 * SP_HBYTES;              // [R][SLAB]
     float* const sBias = (float*)(sW + R * SLAB);       // [Cout]
+    float* const sRed = sBias + a.Cout;                 // [32]: the two maxima's per-wave parts, later the ymax scratch
     const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
     const int li = lane & 31, lh = lane >> 5;
     // DMA pieces of a kernel slice per thread, NP = 3: NT = 4: 768 = 512 + 256 (waves 0-3 two, waves 4-7 one); NT = 2: 384
     // (waves 0-5 one, waves 6-7 none).  NP = 2: NT = 4: 512 (every wave one); NT = 2: 256 (waves 0-3).  A wave's count is static.
     const int nwq = (wv < W1 ? 1 : 0) + (wv < W2 ? 1 : 0);
-    const SpScale sc = sp_scales<NP>(a.xmax, a.wmax);
     const dasr_lds_addr_t ldsH = DASR_LDS_ADDR(sH) + 1024 * wv, ldsW = DASR_LDS_ADDR(sW) + 1024 * wv;
 
     const int xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3;
     const int ibeg = xcd * a.Q;
     const int iend = ibeg + a.Q < a.nitems ? ibeg + a.Q : a.nitems;
     int item = ibeg + jwg;
-    if (item >= iend) return;
+    if (item >= iend) {
+        if (a.ymax) dasr_amax_commit_idle(a.ymax, dasr_flat_wg(), dasr_flat_nwg());
+        return;
+    }
     const int NC = a.Cin >> 4;
     const int pixb = a.Cin * 4, rowb = a.W * pixb;
     const size_t sampb = (size_t)a.H * rowb;
     const char* const zp = (const char*)sp_zero_page;
 
     for (int i = tid; i < a.Cout; i += SP_NTHR) sBias[i] = a.bias ? a.bias[i] : 0.f;
+    sp_scales_gather<NP>(a.xmax, a.wmax, sRed);
     __syncthreads();
+    const SpScale sc = sp_scales_take<NP>(sRed);
 
     int x0, y0, n0, bb;
     auto decode = [&](int it, int& ox0, int& oy0, int& on0, int& ob) {
@@ -414,7 +444,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
         item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
     }
     sp_wait_vm<0>();
-    if (a.ymax) dasr_amax_commit(a.ymax, om);
+    if (a.ymax) dasr_amax_commit(a.ymax, om, sRed, dasr_flat_wg(), dasr_flat_nwg());     // (at most 256 workgroups)
 }
 
 // ---- 32 produced channels (the HR tail: 32 -> 32, 64 -> 32, and the dgrads of 32 -> 32 / 32 -> 128).  With one 32-channel tile a
@@ -433,6 +463,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
     char* const sH = smem;                              // [2][SP_HBYTES]
     char* const sW = smem + 2 * SP_HBYTES;              // [2][WCH]
     float* const sBias = (float*)(sW + 2 * WCH);        // [Cout]
+    float* const sRed = sBias + a.Cout;                 // [32]
     const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
     const int li = lane & 31, lh = lane >> 5;
     const dasr_lds_addr_t ldsH = DASR_LDS_ADDR(sH) + 1024 * wv, ldsW = DASR_LDS_ADDR(sW) + 1024 * wv;
@@ -441,15 +472,19 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
     const int ibeg = xcd * a.Q;
     const int iend = ibeg + a.Q < a.nitems ? ibeg + a.Q : a.nitems;
     int item = ibeg + jwg;
-    if (item >= iend) return;
+    if (item >= iend) {
+        if (a.ymax) dasr_amax_commit_idle(a.ymax, dasr_flat_wg(), dasr_flat_nwg());
+        return;
+    }
     const int NC = a.Cin >> 4;
     const int pixb = a.Cin * 4, rowb = a.W * pixb;
     const size_t sampb = (size_t)a.H * rowb;
     const char* const zp = (const char*)sp_zero_page;
 
     for (int i = tid; i < a.Cout; i += SP_NTHR) sBias[i] = a.bias ? a.bias[i] : 0.f;
+    sp_scales_gather<NP>(a.xmax, a.wmax, sRed);
     __syncthreads();
-    const SpScale sc = sp_scales<NP>(a.xmax, a.wmax);
+    const SpScale sc = sp_scales_take<NP>(sRed);
 
     int x0, y0, n0, bb;
     auto decode = [&](int it, int& ox0, int& oy0, int& on0, int& ob) {
@@ -572,7 +607,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
         item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
     }
     sp_wait_vm<0>();
-    if (a.ymax) dasr_amax_commit(a.ymax, om);
+    if (a.ymax) dasr_amax_commit(a.ymax, om, sRed, dasr_flat_wg(), dasr_flat_nwg());     // (at most 256 workgroups)
 }
 
 // ---- the kernel split: fp32 packed [2][9][Cin][Cout] (plane 0 = HWIO) -> 16-bit image of both modes
@@ -585,7 +620,16 @@ template <int NP>
 __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__ w, unsigned short* __restrict__ ws, int Cin, int Cout,
                                                        const float* __restrict__ wmax) {
     const size_t per_mode = (size_t)9 * NP * Cin * Cout;
-    const float sw = NP == 2 ? sp_pow2(sp_scale_exp(*wmax)) : 1.f;
+    float sw = 1.f;
+    if (NP == 2) {
+        __shared__ float s_red[16];
+        const float m0 = sp_amax_share(wmax);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m0;
+        __syncthreads();
+        float m = s_red[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, s_red[w]);
+        sw = sp_pow2(sp_scale_exp(m));
+    }
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < 2 * (size_t)9 * Cin * Cout; idx += (size_t)gridDim.x * 256) {
         const int mode = idx >= (size_t)9 * Cin * Cout;
         size_t e = idx - (size_t)mode * 9 * Cin * Cout;
@@ -620,10 +664,9 @@ __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__
     }
 }
 
-// ---- max |x| of a tensor, left in device memory for the fp16 scheme's scale (non-negative floats order like their bits:
-// one atomicMax per workgroup on the word; the entry point clears it first)
-__global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, size_t n4, size_t n, unsigned* __restrict__ out) {
-    __shared__ unsigned sm[4];
+// ---- max |x| of a tensor as an amax buffer (dasr_common.h): one partial maximum per workgroup, no atomics, nothing to clear
+__global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, size_t n4, size_t n, float* __restrict__ out) {
+    __shared__ float s_part[16];
     unsigned m = 0;
     const size_t stride = (size_t)gridDim.x * 256;
     // four loads in flight per trip; indices past the end re-read the last piece (harmless for a maximum)
@@ -651,17 +694,24 @@ __global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, siz
             a &= 0x7fffffffu;
             m = m > a ? m : a;
         }
+    // (magnitude bits order like the floats; NaN patterns sort above infinity and are kept as they are)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned t = (unsigned)__shfl_xor((int)m, o);
         m = m > t ? m : t;
     }
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    if ((threadIdx.x & 63) == 0) memcpy(&s_part[threadIdx.x >> 6], &m, 4);
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+        unsigned r[4];
+        memcpy(r, s_part, 16);
+        unsigned a = r[0] > r[1] ? r[0] : r[1], b = r[2] > r[3] ? r[2] : r[3];
         a = a > b ? a : b;
-        if (a) atomicMax(out, a);
+        memcpy(&out[1 + blockIdx.x], &a, 4);
+        if (blockIdx.x == 0) {
+            const int np = (int)gridDim.x;
+            memcpy(out, &np, 4);
+        }
     }
 }
 
@@ -672,6 +722,7 @@ static bool sp_ok(int H, int W, int K, int N) {
 extern "C" int dasr_conv3x3_split_supported(int H, int W, int Cin, int Cout) {
     return (sp_ok(H, W, Cin, Cout) && sp_ok(H, W, Cout, Cin)) ? 1 : 0;      // forward and dgrad
 }
+// (the name is historical: the buffer is written, not raised - see dasr_common.h for its layout)
 int absmax_raise(const float* x, size_t n, float* amax, void* stream) {
     DASR_CHECK_PTR(x); DASR_CHECK_PTR(amax);
     DASR_CHECK_SHAPE(n > 0 && (((size_t)x) & 15) == 0);
@@ -679,15 +730,10 @@ int absmax_raise(const float* x, size_t n, float* amax, void* stream) {
     size_t g = (n4 + 256 * 8 - 1) / (256 * 8);           // ~8 float4 per thread
     if (g > 2048) g = 2048;
     if (g < 1) g = 1;
-    DASR_LAUNCH(k_absmax, dim3((unsigned)g), dim3(256), 0, stream, x, n4, n, (unsigned*)amax);
+    DASR_LAUNCH(k_absmax, dim3((unsigned)g), dim3(256), 0, stream, x, n4, n, amax);
     DASR_RETURN_LAUNCH_STATUS();
 }
-extern "C" int dasr_absmax(const float* x, size_t n, float* amax, void* stream) {
-    DASR_CHECK_PTR(amax);
-    hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    return absmax_raise(x, n, amax, stream);
-}
+extern "C" int dasr_absmax(const float* x, size_t n, float* amax, void* stream) { return absmax_raise(x, n, amax, stream); }
 extern "C" size_t dasr_conv3x3_split_weights_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0) return 0;
     return sizeof(bf16_t) * (size_t)54 * Cin * Cout;
@@ -722,7 +768,7 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
     a.G8 = a.Q < 32 ? a.Q : 32;
     if ((dasr_get_conv_bf16_impl() & 3) == 2) a.G8 = 1;        // tests: one workgroup per XCD walks every item of it
     const size_t lds = 2 * (size_t)SP_HBYTES + (NT == 1 ? 2 * (size_t)(9 * NP * 32 * 32) : 3 * (size_t)(NP * 32 * NT * 32)) +
-                       sizeof(float) * (size_t)a.Cout;
+                       sizeof(float) * (size_t)(a.Cout + 32);
     const dim3 grid(8 * a.G8);
     if (NT == 4)      DASR_LAUNCH((k_conv3x3_split<4, NP>), grid, dim3(SP_NTHR), lds, stream, a);
     else if (NT == 2) DASR_LAUNCH((k_conv3x3_split<2, NP>), grid, dim3(SP_NTHR), lds, stream, a);
@@ -843,7 +889,13 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
     float bsum = 0.f;
     float sx = 1.f, sd = 1.f, inv = 1.f;
     if (NP == 2) {
-        const int kx = sp_scale_exp(*a.xmax), kd = sp_scale_exp(*a.dmax);
+        __shared__ float s_red[32];
+        sp_scales_gather<2>(a.xmax, a.dmax, s_red);
+        __syncthreads();
+        const int nw = (int)(blockDim.x >> 6);
+        float mx = s_red[0], md = s_red[16];
+        for (int w = 1; w < nw; ++w) { mx = fmaxf(mx, s_red[w]); md = fmaxf(md, s_red[16 + w]); }
+        const int kx = sp_scale_exp(mx), kd = sp_scale_exp(md);
         sx = sp_pow2(kx); sd = sp_pow2(kd); inv = sp_pow2(-(kx + kd));
     }
     if (a.zero) {

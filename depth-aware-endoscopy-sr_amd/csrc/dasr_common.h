@@ -85,24 +85,48 @@ static inline unsigned dasr_ew_grid(size_t n, unsigned block = 256) {
 }
 
 // ---- max |.| bookkeeping for the fp16 x 2 split convolutions (conv_split_bf16.hip).  A kernel that PRODUCES a tensor one of
-// them reads keeps a running maximum of the magnitudes it stores (one register per lane) and raises the caller's word
-// once per wave when it is done: the consumer's power-of-two scale then costs no pass over the tensor.  Contract of every
-// `amax` argument: device memory, zero (or any lower bound) on entry, raised atomically - non-negative floats order like
-// their bits.  Values a kernel computes for clamped / shadow lanes are duplicates of stored ones and may take part.
+// them reads keeps a running maximum of the magnitudes it stores (one register per lane); at its end every WORKGROUP stores
+// its maximum into its own word of the caller's buffer - no atomics (same-address atomics cost ~10 ns EACH on the MI355X,
+// measured: one per wave made the 30 us mask layer 104 us), nothing to clear beforehand.  Layout of an `amax` buffer
+// (DASR_AMAX_FLOATS floats): word 0 = n, the number of partial maxima that follow (an int, written by workgroup 0),
+// words 1 .. n = one partial maximum per workgroup of the producing launch (n <= DASR_AMAX_MAX_PARTS); the consumer takes
+// the maximum of them in its prologue (sp_amax_read).  Values a kernel computes for clamped / shadow lanes are duplicates
+// of stored ones and may take part.
 __device__ __forceinline__ float dasr_amax1(float m, float v) { return fmaxf(m, fabsf(v)); }
 __device__ __forceinline__ float dasr_amax4(float m, float4 o) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
 }
-// every lane of the wave must arrive (no early-exited lanes): butterfly over the 64 lanes, one atomic per wave
-__device__ __forceinline__ void dasr_amax_commit(float* amax, float m) {
+// EVERY thread of the workgroup must arrive (no early-exited lanes or waves).  s_part: >= 16 floats of LDS nothing else is
+// using at that point; wg / nwg: this workgroup's index in, and the size of, the flattened grid.
+__device__ __forceinline__ void dasr_amax_commit(float* amax, float m, float* s_part, unsigned wg, unsigned nwg) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) {
-        unsigned u;
-        memcpy(&u, &m, 4);
-        atomicMax((unsigned*)amax, u);
+    __syncthreads();                                   // (s_part may alias a buffer the workgroup was still reading)
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (int)((blockDim.x * blockDim.y * blockDim.z + 63) >> 6);
+        float r = s_part[0];
+        for (int w = 1; w < nw; ++w) r = fmaxf(r, s_part[w]);
+        amax[1 + wg] = r;
+        if (wg == 0) {
+            const int n = (int)nwg;
+            memcpy(amax, &n, 4);
+        }
     }
 }
+// a workgroup that leaves before doing any work still owns a word
+__device__ __forceinline__ void dasr_amax_commit_idle(float* amax, unsigned wg, unsigned nwg) {
+    if (threadIdx.x == 0) {
+        amax[1 + wg] = 0.f;
+        if (wg == 0) {
+            const int n = (int)nwg;
+            memcpy(amax, &n, 4);
+        }
+    }
+}
+__device__ __forceinline__ unsigned dasr_flat_wg() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+__device__ __forceinline__ unsigned dasr_flat_nwg() { return gridDim.x * gridDim.y * gridDim.z; }
 
 __device__ __forceinline__ float dasr_act(float v, int act) {
     if (act == DASR_ACT_RELU) return v > 0.f ? v : 0.f;

@@ -16,6 +16,7 @@
 // out accesses are 256-byte coalesced rows and the LDS reads of D are conflict-free (lane = channel).
 #include "dasr_common.h"
 #include "bf16.h"
+#include "conv_kernels.h"
 
 #define SEAN_TH 8
 #define SEAN_TW 32
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const T* __restric
                                                   const float* __restrict__ bias_b, const float* __restrict__ alpha_g,
                                                   const float* __restrict__ alpha_b, const T* __restrict__ residual,
                                                   T* __restrict__ out, int relu, float eps,
-                                                  const int* __restrict__ onehot_flag, float* __restrict__ amax) {
+                                                  const int* __restrict__ onehot_flag) {
     if (onehot_flag && *onehot_flag == 0) return;   // one-hot masks: k_sean_fwd_onehot does the work
     DASR_DYN_SMEM(smem);
     float* sD = (float*)smem;
@@ -93,14 +94,12 @@ __global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const T* __restric
     __syncthreads();
     int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
     int c = c0 + cl;
-    const bool livec = c < g.C;                      // (no early return: the wave meets again in dasr_amax_commit)
-    if (!livec) c = 0;
+    if (c >= g.C) return;
     float a_g = alpha_g[0], a_b = alpha_b[0];
     float mu = mean[(size_t)b * g.C + c];
     float s = dasr_double_in_scale(var[(size_t)b * g.C + c], eps);
     float bg = bias_g[c], bb = bias_b[c];
-    float om = 0.f;
-    for (int lp = pl; livec && lp < SEAN_TH * SEAN_TW; lp += 4) {
+    for (int lp = pl; lp < SEAN_TH * SEAN_TW; lp += 4) {
         int ly = lp / SEAN_TW, lx = lp % SEAN_TW;
         int y = y0 + ly, x = x0 + lx;
         if (y >= g.H || x >= g.W) continue;
@@ -117,9 +116,7 @@ __global__ void __launch_bounds__(256) k_sean_fwd(SeanGeom g, const T* __restric
         if (residual) o += ld1(residual + p * g.C + c);
         if (relu) o = o > 0.f ? o : 0.f;
         st1(out + p * g.C + c, o);
-        om = dasr_amax1(om, o);
     }
-    if (amax) dasr_amax_commit(amax, om);
 }
 
 // ---------------------------------------------------------------------------------------- backward
@@ -141,8 +138,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restr
                                                     float* __restrict__ dbias_g, float* __restrict__ dbias_b,
                                                     float* __restrict__ dalpha_g, float* __restrict__ dalpha_b,
                                                     T* __restrict__ dres, float* __restrict__ S, int relu,
-                                                    float eps, const int* __restrict__ onehot_flag,
-                                                    float* __restrict__ dgb2_amax) {
+                                                    float eps, const int* __restrict__ onehot_flag) {
     if (onehot_flag && *onehot_flag == 0) return;
     DASR_DYN_SMEM(smem);
     float* sD = (float*)smem;
@@ -164,7 +160,6 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restr
     float s = live ? dasr_double_in_scale(var[(size_t)b * g.C + c], eps) : 0.f;
     float bg = live ? bias_g[c] : 0.f, bb = live ? bias_b[c] : 0.f;
     float S1 = 0.f, S2 = 0.f, dag = 0.f, dab = 0.f, dbg = 0.f, dbb = 0.f;
-    float gm = 0.f;                                  // running max |dgb2| of this lane
     int MW = SEAN_TW + 2, MH = SEAN_TH + 2;
     if (live)
         for (int lp = pl; lp < SEAN_TH * SEAN_TW; lp += 4) {
@@ -186,7 +181,6 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restr
             float dgam = g0 * xh, dbet = g0;
             st1(dgb2 + p * 2 * g.C + c, (1.f - a_g) * dgam);
             st1(dgb2 + p * 2 * g.C + g.C + c, (1.f - a_b) * dbet);
-            gm = dasr_amax1(dasr_amax1(gm, (1.f - a_g) * dgam), (1.f - a_b) * dbet);
             dag = fmaf(dgam, g1 - g2, dag);
             dab = fmaf(dbet, b1 - b2, dab);
             float dg1 = a_g * dgam, db1 = a_b * dbet;
@@ -241,7 +235,6 @@ __global__ void __launch_bounds__(256) k_sean_bwd_a(SeanGeom g, const T* __restr
         float v = sdD[i];
         if (c0 + cl2 < g.C && v != 0.f) atomicAdd(&dD[((size_t)b * 18 * K + r) * g.C + c0 + cl2], v);
     }
-    if (dgb2_amax) dasr_amax_commit(dgb2_amax, gm);
 }
 
 // dt = s*(dxhat - S1/N) + s'(var)*(2/N)*(t-mean)*S2; float4 per lane when C % 4 == 0 (per-(b,c) constants are
@@ -251,6 +244,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const T* __restrict__ t, con
                                                     const float* __restrict__ var, const float* __restrict__ S,
                                                     T* __restrict__ dt, int HW, int C, size_t n, float eps,
                                                     float* __restrict__ amax) {
+    __shared__ float s_part[16];
     const float invN = 1.0f / (float)HW;
     float om = 0.f;
     if ((C & 3) == 0) {
@@ -275,7 +269,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const T* __restrict__ t, con
             st4(dt + 4 * i, dv);
             om = dasr_amax4(om, dv);
         }
-        if (amax) dasr_amax_commit(amax, om);
+        if (amax) dasr_amax_commit(amax, om, s_part, dasr_flat_wg(), dasr_flat_nwg());
         return;
     }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -289,7 +283,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b(const T* __restrict__ t, con
         st1(dt + i, o);
         om = dasr_amax1(om, o);
     }
-    if (amax) dasr_amax_commit(amax, om);
+    if (amax) dasr_amax_commit(amax, om, s_part, dasr_flat_wg(), dasr_flat_nwg());
 }
 
 
@@ -301,6 +295,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b_rows(const T* __restrict__ t
                                                          const float* __restrict__ var, const float* __restrict__ S,
                                                          T* __restrict__ dt, int HW, int C, float eps,
                                                          float* __restrict__ amax) {
+    __shared__ float s_part[16];
     const int C4 = C >> 2, q = threadIdx.x % C4, pl = threadIdx.x / C4, npl = 256 / C4;
     const int b = blockIdx.y, c = 4 * q;
     const float invN = 1.0f / (float)HW;
@@ -327,7 +322,7 @@ __global__ void __launch_bounds__(256) k_sean_bwd_b_rows(const T* __restrict__ t
         st4(db + (size_t)p * C, dv);
         om = dasr_amax4(om, dv);
     }
-    if (amax) dasr_amax_commit(amax, om);
+    if (amax) dasr_amax_commit(amax, om, s_part, dasr_flat_wg(), dasr_flat_nwg());
 }
 
 // =====================================================================================================
@@ -548,7 +543,10 @@ __global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_f
     const int first = blockIdx.x * base + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
     int last = first + base + ((int)blockIdx.x < rem ? 1 : 0);
     if (last > g.B * tiles_per_sample) last = g.B * tiles_per_sample;
-    if (first >= last) return;
+    if (first >= last) {
+        if (AMAX) dasr_amax_commit_idle(amax, dasr_flat_wg(), dasr_flat_nwg());
+        return;
+    }
     auto tile_of = [&](int tt) {
         const int tile = tt % tiles_per_sample;
         return SeanTile{tt / tiles_per_sample, (tile / tiles_x) * TH, (tile % tiles_x) * SF_TW};
@@ -639,7 +637,7 @@ __global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_f
         }
         consume(NG - 1, fb);
     }
-    if (AMAX) dasr_amax_commit(amax, om);
+    if (AMAX) dasr_amax_commit(amax, om, sD, dasr_flat_wg(), dasr_flat_nwg());     // (sD: dead after the last tile)
 }
 
 // ---- backward, pass A, one-hot -------------------------------------------------------------------------
@@ -962,8 +960,8 @@ __global__ void __launch_bounds__(512) k_sean_bwd_a_onehot(
             if (i + 1 <= n) iteration(i + 1, DEEP ? setB : setA);
         }
     }
-    // (here, where every lane of every wave is still on the same path)
-    if (AMAX) dasr_amax_commit(dgb2_amax, gm);
+    // (here, where every lane of every wave is still on the same path; sred is written only below)
+    if (AMAX) dasr_amax_commit(dgb2_amax, gm, sred, dasr_flat_wg(), dasr_flat_nwg());
     // ---- per-channel sums: reduce over the 4 pixel sub-lanes (lanes l, l+16, l+32, l+48), then over the 8 waves
     float vals[18] = {S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, dbg.x, dbg.y, dbg.z, dbg.w,
                       dbb.x, dbb.y, dbb.z, dbb.w, dag, dab};
@@ -1058,6 +1056,9 @@ static int sean_fwd_impl(const T* t, const float* mean, const float* var, const 
     SeanGeom g{B, H, W, C, K};
     const bool fast = region != nullptr && (C % 4) == 0;
     const bool fast_only = fast && onehot_flag == nullptr;   // the caller vouches for one-hot masks
+    // max |out|: kept by the gather kernel itself when it is the only one launched (at most 768 workgroups); otherwise a
+    // pass over `out` afterwards (which of the two kernels works is decided on the device)
+    const bool fused_amax = sizeof(T) == 4 && out_amax != nullptr && fast_only;
     if (fast) {
         int tiles = B * ((W + SF_TW - 1) / SF_TW) * ((H + SF_TH - 1) / SF_TH);
         int slices = (int)dasr_cdiv(C, 64);
@@ -1068,7 +1069,7 @@ static int sean_fwd_impl(const T* t, const float* mean, const float* var, const 
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
 #define SEAN_FWD_GO(RELU, RES)                                                                                     \
     do {                                                                                                           \
-        if (sizeof(T) == 4 && out_amax)                                                                            \
+        if (fused_amax)                                                                                            \
             DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES, T, sizeof(T) == 4>), dim3(nwg, slices), dim3(256), lds, stream, g, t, \
                         mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, eps, per, out_amax); \
         else                                                                                                       \
@@ -1084,8 +1085,10 @@ static int sean_fwd_impl(const T* t, const float* mean, const float* var, const 
         size_t lds = sizeof(float) * (size_t)(2 * 9 * K * 64 + K * (SEAN_TH + 2) * (SEAN_TW + 2));
         DASR_LAUNCH((k_sean_fwd<T>), dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, t, mean, var, gb2, mask, D,
                     bias_g, bias_b, alpha_g, alpha_b, residual, out, relu, eps,
-                    fast ? onehot_flag : (const int*)nullptr, sizeof(T) == 4 ? out_amax : (float*)nullptr);
+                    fast ? onehot_flag : (const int*)nullptr);
     }
+    if (sizeof(T) == 4 && out_amax && !fused_amax)
+        return absmax_raise((const float*)out, (size_t)B * H * W * C, out_amax, stream);
     DASR_RETURN_LAUNCH_STATUS();
 }
 
@@ -1183,11 +1186,11 @@ static int sean_bwd_impl(const T* dout, const T* out, const T* t, const float* m
         size_t lds = (size_t)sean_bwd_lds_bytes(K, TH, NP);
         if (lds > 160 * 1024) return DASR_E_UNSUPPORTED;
         constexpr bool F32 = sizeof(T) == 4;
-        if (F32 && dgb2_amax && big)
+        if (F32 && dgb2_amax && fast_only && big)
             DASR_LAUNCH((k_sean_bwd_a_onehot<T, TH_BIG, F32>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
                         mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
                         dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles, dgb2_amax);
-        else if (F32 && dgb2_amax)
+        else if (F32 && dgb2_amax && fast_only)
             DASR_LAUNCH((k_sean_bwd_a_onehot<T, TH_SMALL, F32>), dim3(nblk, B, dasr_cdiv(C, 64)), dim3(512), lds, stream, g, dout, out, t,
                         mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, slabs, dbias_g,
                         dbias_b, dalpha_g, dalpha_b, dres, S, relu, eps, ntiles, dgb2_amax);
@@ -1208,13 +1211,18 @@ static int sean_bwd_impl(const T* dout, const T* out, const T* t, const float* m
         size_t lds = sean_bwd_general_lds(K);
         DASR_LAUNCH((k_sean_bwd_a<T>), dim3(tiles, B, dasr_cdiv(C, 64)), dim3(256), lds, stream, g, dout, out, t, mean, var,
                     gb2, mask, D, bias_g, bias_b, alpha_g, alpha_b, dt, dgb2, dD, dbias_g, dbias_b, dalpha_g, dalpha_b,
-                    dres, S, relu, eps, fast ? onehot_flag : (const int*)nullptr, sizeof(T) == 4 ? dgb2_amax : (float*)nullptr);
+                    dres, S, relu, eps, fast ? onehot_flag : (const int*)nullptr);
+    }
+    if (sizeof(T) == 4 && dgb2_amax && !fast_only) {       // (which kernel wrote dgb2 was decided on the device)
+        int rc = absmax_raise((const float*)dgb2, (size_t)B * H * W * 2 * C, dgb2_amax, stream);
+        if (rc) return rc;
     }
     size_t n = (size_t)B * H * W * C;
     if ((C & 3) == 0 && (256 % (C / 4)) == 0 && B <= 65535) {
         const int npl = 256 / (C / 4);
         unsigned gx = dasr_cdiv((size_t)H * W, npl * 8);     // eight pixels per thread
         if (gx < 1) gx = 1;
+        if (dt_amax && (size_t)gx * B > DASR_AMAX_MAX_PARTS) gx = DASR_AMAX_MAX_PARTS / B;   // (one partial maximum per workgroup)
         DASR_LAUNCH((k_sean_bwd_b_rows<T>), dim3(gx, B), dim3(256), 0, stream, t, mean, var, S, dt, H * W, C, eps,
                     sizeof(T) == 4 ? dt_amax : (float*)nullptr);
     } else {

@@ -179,7 +179,7 @@ def _amax_t(t):
 
 
 def want_amax(tape, like, shape=None):
-    """A zeroed slot for a producer kernel to raise (Tape.amax_slot) when the tensor it is about to write - shaped ``shape``
+    """An amax buffer for a producer kernel to fill (ops.amax_buffer) when the tensor it is about to write - shaped ``shape``
     (default: like ``like``), on ``like``'s device - can be the operand of an fp16 x 2 split convolution, else None: NHWC
     fp32 on the fp32 path, at least SPLIT_MIN_PIXELS pixels."""
     if not (SPLIT_BF16 and SPLIT_PIECES == 2 and FUSE_AMAX) or like.dtype != torch.float32 or tape.act_dtype != torch.float32:
@@ -187,7 +187,7 @@ def want_amax(tape, like, shape=None):
     shape = tuple(like.shape) if shape is None else shape
     if len(shape) != 4 or shape[0] * shape[1] * shape[2] < SPLIT_MIN_PIXELS:
         return None
-    return tape.amax_slot(like)
+    return ops.amax_buffer(like)
 
 
 def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.ACT_NONE, ps_r=1, residual=None,

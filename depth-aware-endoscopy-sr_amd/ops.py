@@ -93,8 +93,25 @@ def resize_nearest_u8(region, H, W):
 
 
 # ---- max |.| of a tensor, carried on the tensor (fp16 x 2 split convolutions) ---------------------------------------
-# A producer kernel that was handed a zeroed device float raises it to the max |.| of what it stores (dasr.h, *_amax
-# arguments); the float then travels with the tensor as an attribute.  Every op that writes into an existing tensor drops it.
+# A producer kernel that is handed an amax buffer (dasr.h: DASR_AMAX_FLOATS floats - a count and one partial maximum per
+# workgroup) fills it while it stores its output; the buffer then travels with the tensor as an attribute.  Every op that
+# writes into an existing tensor drops it.
+AMAX_FLOATS = 4097
+
+
+def amax_buffer(like):
+    """An (uninitialised) amax buffer on ``like``'s device: nothing to clear, the producer writes every word it declares."""
+    return torch.empty((AMAX_FLOATS,), dtype=torch.float32, device=like.device)
+
+
+def amax_value(buf):
+    """Host-side read of an amax buffer (tests and tools only: the kernels never need it on the host)."""
+    h = buf.detach().cpu()
+    n = int(h[:1].view(torch.int32).item())
+    assert 1 <= n < AMAX_FLOATS, n
+    return float(h[1:1 + n].max().item())
+
+
 def set_amax(t, amax):
     if amax is not None:
         t._dasr_amax = amax
@@ -460,9 +477,9 @@ def conv3x3_dgrad_split(dconv, ws, x_shape, out=None):
 
 # ---- the same with two fp16 pieces / three products; every tensor operand comes with its max |.| in device memory ----
 def absmax(x):
-    """max |x| as a 1-element device tensor (the fp16 scheme's kernels derive their power-of-two scale from it)."""
+    """max |x| as an amax buffer on the device (the fp16 scheme's kernels derive their power-of-two scale from it)."""
     assert x.dtype == torch.float32 and x.is_contiguous()
-    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    out = amax_buffer(x)
     _call("dasr_absmax", _p(x), x.numel(), _p(out))
     return out
 

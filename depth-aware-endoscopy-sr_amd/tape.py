@@ -47,30 +47,6 @@ class Tape:
         self.fold_cache = None      # inference only: {param name: (versions, packed tensor)}, see graph._folded
         self.marks = []             # node counts at which the forward plan called mark(): gradient-bucket boundaries
         self.on_mark = None         # called during backward() each time the tape has unwound below a mark
-        self._amax_pool = None      # [tensor of zeros, next index, event | None, {stream ids that have waited for it}]
-
-    def amax_slot(self, like):
-        """A zeroed one-element device float for a producer kernel to raise to the max |.| of what it stores (ops.set_amax).
-        Slots are cut from pools of 256 zeros (one fill kernel per pool instead of a memset per slot); a stream other than
-        the one that zeroed the pool waits for that fill once."""
-        import torch
-        pool = self._amax_pool
-        if pool is None or pool[1] >= pool[0].numel() or pool[0].device != like.device:
-            z = torch.zeros(256, dtype=torch.float32, device=like.device)
-            ev, sid = None, 0
-            if z.is_cuda:
-                cur = torch.cuda.current_stream()
-                ev, sid = cur.record_event(), cur.cuda_stream
-            pool = self._amax_pool = [z, 0, ev, {sid}]
-        if pool[2] is not None:
-            cur = torch.cuda.current_stream()
-            if cur.cuda_stream not in pool[3]:
-                cur.wait_event(pool[2])
-                pool[0].record_stream(cur)
-                pool[3].add(cur.cuda_stream)
-        i = pool[1]
-        pool[1] = i + 1
-        return pool[0][i:i + 1]
 
     def record(self, fn):
         if self.enabled:

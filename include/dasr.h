@@ -91,8 +91,8 @@ int dasr_weight_pack_bwd(const float* dw_hwio, const float* v, const float* g, c
  *   ps_r > 1 writes y as [B][Ho*r][Wo*r][Cout/r^2] with
  *   y[b, oy*r+i, ox*r+j, c] = act(conv[b,oy,ox, c*r*r + i*r + j])   (bit-exact index map of nn.PixelShuffle).
  * bias, residual may be NULL.
- * y_amax (may be NULL): max |y| for a following fp16 x 2 split convolution - zero on entry, raised atomically (by the mask
- * layer's kernel while it stores; by a pass over y after every other kernel).  See dasr_absmax.
+ * y_amax (may be NULL): amax buffer (see dasr_absmax) for max |y|, filled by the mask layer's kernel while it stores and
+ * by a pass over y after every other kernel.
  */
 int dasr_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, const float* residual, float* y, float* y_amax,
                     int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
@@ -108,7 +108,7 @@ int dasr_conv2d_fwd_stats(const float* x, const float* w, const float* bias, flo
                           void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
 
 /* Backward of the epilogue: dconv[b,oy,ox,cc] = dy[...shuffled...] * act'(y[...]) (y = saved forward output).
- * dconv_amax (may be NULL): max |dconv|, zero on entry, raised atomically by the kernel (see dasr_absmax). */
+ * dconv_amax (may be NULL): amax buffer (see dasr_absmax) for max |dconv|, filled by the kernel. */
 int dasr_conv2d_epilogue_bwd(const float* dy, const float* y, float* dconv, float* dconv_amax, int B, int Ho, int Wo,
                              int Cout, int act, int ps_r, void* stream);
 /* dx (+)= conv-transpose of dconv with w; accumulate != 0 adds into dx. */
@@ -173,13 +173,20 @@ int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, float* dw_hwio,
  * dropped term is 2^-24 relative, and only half as many partial sums are rounded into the fp32 accumulator: measured
  * against float64 the result is closer than both the bf16 x 3 scheme and the exact-fp32 MFMA kernels.  fp16's narrow range
  * is handled by a power-of-two scale per tensor that puts its largest magnitude in [2^14, 2^15):
- *   dasr_absmax:     *amax = max |x| over n floats (x 16-byte aligned); cleared and written on the stream (device memory:
- *                    the kernels below derive the scale from its exponent bits, nothing is read back by the host)
+ *   dasr_absmax:     max |x| over n floats (x 16-byte aligned) into an AMAX BUFFER: DASR_AMAX_FLOATS floats of device
+ *                    memory, word 0 = the number n of partial maxima that follow (int), words 1 .. n = one partial maximum
+ *                    per workgroup of the producing launch.  No atomics, nothing to clear, nothing read back by the host:
+ *                    the kernels below take the maximum of the parts in their prologue and derive the scale from its
+ *                    exponent bits.  Every `*max` / `*_amax` argument of this header is such a buffer; the producer-side
+ *                    ones (y_amax, out_amax, dt_amax, ...) may be NULL and are filled by the kernel that writes the
+ *                    tensor - no extra pass over it - or, where that kernel does not keep a maximum, by a follow-up pass
+ *                    inside the entry point
  *   split2_weights:  wmax = dasr_absmax of the packed kernel's plane 0 (9 Cin Cout floats); image: split2_weights_bytes
  *   fwd / dgrad / wgrad_split2: as the functions above plus the maxima of their tensor operands (xmax of x, dmax of dconv);
- *                    y_amax (may be NULL): max |y| of what the forward stores, for the NEXT split convolution - zero on
- *                    entry, raised atomically from the epilogue (the contract of every *_amax argument of this header)
+ *                    y_amax (may be NULL): amax buffer for max |y| of what the forward stores, for the NEXT split convolution
  * Same nn.Conv2d calls replaced (normalization.py:41-42,73-74; sftmd_arch.py:811-820 and the upscale tail :891-909). */
+#define DASR_AMAX_MAX_PARTS 4096
+#define DASR_AMAX_FLOATS (1 + DASR_AMAX_MAX_PARTS)
 int dasr_absmax(const float* x, size_t n, float* amax, void* stream);
 size_t dasr_conv3x3_split2_weights_bytes(int Cin, int Cout);
 int dasr_conv3x3_split2_weights(const float* w_packed, const float* wmax, unsigned short* w_split, int Cin, int Cout,
@@ -248,9 +255,8 @@ int dasr_sean_fwd(const float* t, const float* mean, const float* var, const flo
 /* Backward. Inputs as forward plus dout and the saved forward output `out` (for the ReLU mask).
  * Outputs: dt [B,H,W,C]; dgb2 [B,H,W,2C]; dD [B,2,9,K,C]; dbias_gamma, dbias_beta [C]; dalpha_gamma, dalpha_beta [1];
  * dres (may be NULL; written = dout*relu') ; workspace: dasr_sean_bwd_workspace() bytes.
- * out_amax / dt_amax / dgb2_amax (fp32 entry points, each may be NULL): max |.| of the tensor just written, for the
- * fp16 x 2 split convolution that reads it next - ZERO (or a lower bound) on entry, raised atomically by the producing
- * kernel itself (no extra pass over the tensor; see dasr_absmax). */
+ * out_amax / dt_amax / dgb2_amax (fp32 entry points, each may be NULL): amax buffers (see dasr_absmax) that receive
+ * max |.| of the tensor just written, for the fp16 x 2 split convolution that reads it next. */
 size_t dasr_sean_bwd_workspace(int B, int H, int W, int C, int K);
 int dasr_sean_bwd(const float* dout, const float* out, const float* t, const float* mean, const float* var,
                   const float* gb2, const float* mask, const unsigned char* region, const int* onehot_flag,

@@ -1133,14 +1133,16 @@ def check_absmax(device, seed=3):
     for n in (4, 7, 1024, 4099, 300001):
         x = torch.randn(n + 4, generator=gen)[:n].clone()
         x[n // 2] = -77.5 if n % 2 else 91.25
-        got = ops.absmax(x.to(device)).cpu().item()
+        got = ops.amax_value(ops.absmax(x.to(device)))
         assert got == x.abs().max().item(), (n, got)
-    assert ops.absmax(torch.zeros(64).to(device)).cpu().item() == 0.0
+    assert ops.amax_value(ops.absmax(torch.zeros(64).to(device))) == 0.0
+    big = torch.randn(3 * 1024 * 1024 + 5, generator=gen)          # many workgroups: many partial maxima
+    assert ops.amax_value(ops.absmax(big.to(device))) == big.abs().max().item()
     return dict(ok=True)
 
 
 def check_fused_amax(device, seed=11):
-    """Every producer kernel that leaves max |.| of what it stores behind (the *_amax arguments of dasr.h) against torch's
+    """Every producer kernel that leaves max |.| of what it stores behind (the *_amax buffers of dasr.h) against torch's
     abs().max() of the tensor it wrote - EXACT (the kernels take maxima of the stored values themselves): SEAN forward
     (one-hot and soft masks, with / without ReLU and residual), SEAN backward (dt, dgb2), the mask layer, a convolution
     whose kernel does not track it (follow-up pass inside the entry point), the activation / PixelShuffle backward in its
@@ -1148,7 +1150,7 @@ def check_fused_amax(device, seed=11):
     gen = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=gen)
     dev = lambda t: t.to(device)
-    z = lambda: torch.zeros(1).to(device)
+    z = lambda: ops.amax_buffer(torch.zeros(1).to(device)).fill_(float("nan"))       # (poisoned: the producer must write every word it declares)
     amx = lambda t: t.detach().abs().max().item()
     out = {}
     # ---- SEAN
@@ -1167,15 +1169,15 @@ def check_fused_amax(device, seed=11):
             a = z()
             y = ops.sean_fwd(dev(t), mean, var, dev(gb2), mask, region, flag, dev(D), dev(bg), dev(bb), dev(ag), dev(ab),
                              dev(r) if r is not None else None, relu, amax=a)
-            assert ops.get_amax(y) is a and a.item() == amx(y), ("sean fwd", soft, relu, r is not None, a.item(), amx(y))
+            assert ops.get_amax(y) is a and ops.amax_value(a) == amx(y), ("sean fwd", soft, relu, r is not None, ops.amax_value(a), amx(y))
             y0 = ops.sean_fwd(dev(t), mean, var, dev(gb2), mask, region, flag, dev(D), dev(bg), dev(bb), dev(ag), dev(ab),
                               dev(r) if r is not None else None, relu)
             assert torch.equal(y, y0) and ops.get_amax(y0) is None
             a1, a2 = z(), z()
             rr = ops.sean_bwd(dev(dout), y, dev(t), mean, var, dev(gb2), mask, region, flag, dev(D), dev(bg), dev(bb), dev(ag),
                               dev(ab), relu, r is not None, dt_amax=a1, dgb2_amax=a2)
-            assert a1.item() == amx(rr[0]) and a2.item() == amx(rr[1]), ("sean bwd", soft, relu, a1.item(), amx(rr[0]), a2.item(), amx(rr[1]))
-            assert a1.item() > 0 and a2.item() > 0
+            assert ops.amax_value(a1) == amx(rr[0]) and ops.amax_value(a2) == amx(rr[1]), ("sean bwd", soft, relu, ops.amax_value(a1), amx(rr[0]), ops.amax_value(a2), amx(rr[1]))
+            assert ops.amax_value(a1) > 0 and ops.amax_value(a2) > 0
     out["sean"] = True
     # ---- the mask layer (kernel tracks it) and a 3 -> 32 layer on the same entry point, a 3x3 MFMA convolution (follow-up pass)
     for (cin, cout, act) in ((1, 128, ops.ACT_RELU), (3, 32, ops.ACT_LRELU), (32, 64, ops.ACT_NONE)):
@@ -1184,14 +1186,14 @@ def check_fused_amax(device, seed=11):
         b = dev(rn(cout))
         a = z()
         y = ops.conv2d_fwd(dev(x), w, b, act=act, amax=a)
-        assert a.item() == amx(y), ("conv fwd amax", cin, cout, a.item(), amx(y))
+        assert ops.amax_value(a) == amx(y), ("conv fwd amax", cin, cout, ops.amax_value(a), amx(y))
         assert torch.equal(y, ops.conv2d_fwd(dev(x), w, b, act=act))
     # ---- activation / PixelShuffle backward
     for (Cq, act, ps, Hs, Ws) in ((8, 1, 1, 6, 5), (8, 2, 2, 6, 5), (4, 2, 3, 5, 7), (3, 2, 1, 5, 7)):
         yv, dyv = rn(2, Hs * ps, Ws * ps, Cq), rn(2, Hs * ps, Ws * ps, Cq) * 1e-4
         a = z()
         d = ops.conv2d_epilogue_bwd(dev(dyv), dev(yv), Hs, Ws, Cq * ps * ps, act, ps, amax=a)
-        assert a.item() == amx(d), ("epilogue bwd amax", Cq, act, ps, a.item(), amx(d))
+        assert ops.amax_value(a) == amx(d), ("epilogue bwd amax", Cq, act, ps, ops.amax_value(a), amx(d))
         assert torch.equal(d, ops.conv2d_epilogue_bwd(dev(dyv), dev(yv), Hs, Ws, Cq * ps * ps, act, ps))
     # ---- fp16 x 2 split forward
     for (cin, cout, act, with_res, ps, Hs, Ws) in ((64, 64, 0, False, 1, 17, 35), (32, 128, 1, True, 1, 9, 33), (32, 128, 2, False, 2, 9, 33),
@@ -1204,7 +1206,7 @@ def check_fused_amax(device, seed=11):
         xm = ops.absmax(dev(x))
         a = z()
         y = ops.conv3x3_fwd_split2(dev(x), xm, ws, b, cout, r, act, ps, amax=a)
-        assert a.item() == amx(y), ("split fwd amax", cin, cout, act, ps, a.item(), amx(y))
+        assert ops.amax_value(a) == amx(y), ("split fwd amax", cin, cout, act, ps, ops.amax_value(a), amx(y))
         assert torch.equal(y, ops.conv3x3_fwd_split2(dev(x), xm, ws, b, cout, r, act, ps))
     # ---- an in-place writer drops what the tensor carried
     y = ops.conv2d_fwd(dev(rn(1, 5, 5, 1)), ops.pack_hwio(dev(rn(3, 3, 1, 8))), None, amax=z())
@@ -1216,8 +1218,8 @@ def check_fused_amax(device, seed=11):
 
 def check_fused_amax_net(device, case_name="x8_nb4"):
     """Whole net with the fp16 x 2 split convolutions forced on: the maxima left behind by the producing kernels
-    (graph.FUSE_AMAX) against one dasr_absmax pass per operand - the same scales, so output and every gradient BIT-identical;
-    and the fused run must launch far fewer absmax passes."""
+    (graph.FUSE_AMAX) against one dasr_absmax pass per operand - the same scales, so the output is BIT-identical (and, on the
+    deterministic emulator, every gradient); and the fused run must launch far fewer absmax passes."""
     from dasr_amd import graph
     case = [c for c in DEPTHNET_CASES if c["name"] == case_name][0]
     net, cfg = build_net(case, device)
@@ -1247,8 +1249,13 @@ def check_fused_amax_net(device, case_name="x8_nb4"):
         ops.absmax = orig_absmax
         graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.FUSE_AMAX = old
     assert torch.equal(res[True][0], res[False][0]), "forward differs between fused and separate maxima"
+    # (the GPU's weight / bias gradient reductions end in float atomics: two identical runs differ in the last bits there)
     for k, gten in res[False][1].items():
-        assert torch.equal(res[True][1][k], gten), ("gradient differs", k)
+        if device == "cpu":
+            assert torch.equal(res[True][1][k], gten), ("gradient differs", k)
+        else:
+            d = (res[True][1][k] - gten).double().norm().item()
+            assert d <= 2e-5 * max(gten.double().norm().item(), 1e-30) or any(z in k for z in ZERO_GRAD_KEYS), ("gradient differs", k, d)
     assert calls[True] * 2 <= calls[False], calls          # (what is left: the kernels' own maxima, a few unfused producers)
     return dict(absmax_passes_fused=calls[True], absmax_passes_separate=calls[False])
 
