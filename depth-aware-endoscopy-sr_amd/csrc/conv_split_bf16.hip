@@ -279,12 +279,15 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     constexpr int W1 = WP >= 512 ? 8 : WP / 64;                              // waves 0 .. W1-1 carry pieces 0 .. 511
     constexpr int W2 = WP > 512 ? (WP - 512) / 64 : 0;                       // waves 0 .. W2-1 a second one (pieces 512 ..)
     char* const sH = smem;                              // [2][SP_HBYTES]
-    // kernel slices: a ring of R slots running D steps ahead of the MFMAs.  (Measured for NP = 2, whose 8 KB slices would
-    // leave room for conv_bf16_v2.hip's nine slots / five steps ahead: no change on any shape - the slices are not what a
-    // step waits for.)
+    // K-step = TPS taps of one 16-channel chunk between two barriers.  NP = 3: one tap (48 MFMAs per wave at NT = 4).  NP = 2:
+    // a whole kernel ROW (three taps, 72 MFMAs): with half the products a one-tap step was as long as its own wait + barrier +
+    // operand reads, and the compiler cannot overlap those across a barrier; inside a three-tap step it pipelines the reads
+    // and splits of one tap under the MFMAs of the previous one.  Kernel slices: a ring of R step-slots (TPS slices each)
+    // running D steps ahead.  (Measured for one-tap steps at NP = 2: nine slots / five steps ahead instead - no change.)
+    constexpr int TPS = NP == 2 ? 3 : 1, NS = 9 / TPS;
     constexpr int R = 3, D = 2;
-    char* const sW = smem + 2 * SP_HBYTES;              // [R][SLAB]
-    float* const sBias = (float*)(sW + R * SLAB);       // [Cout]
+    char* const sW = smem + 2 * SP_HBYTES;              // [R][TPS][SLAB]
+    float* const sBias = (float*)(sW + R * TPS * SLAB); // [Cout]
     float* const sRed = sBias + a.Cout;                 // [32]: the two maxima's per-wave parts, later the ymax scratch
     const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
     const int li = lane & 31, lh = lane >> 5;
@@ -345,13 +348,23 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
         const char* src = ((hok >> u) & 1u) ? hxb + hoff[u] + 64 * cc : zp;
         DASR_GLDS16(src, ldsH + buf * SP_HBYTES + 1024 * SP_NWV * u);
     };
-    // slice of K-step (slice index ns, tap, chunk cc): contiguous SLAB bytes at ((ns * 9 + tap) * NC + cc) * SLAB
-    auto w_issue = [&](int cc, int tap, int fn0) {
-        const char* src = (const char*)a.ws + (size_t)(((fn0 / NTILE) * 9 + tap) * NC + cc) * SLAB + 16 * tid;
-        const dasr_lds_addr_t dst = ldsW + (tap % R) * SLAB;
-        if (wv < W1) DASR_GLDS16(src, dst);                                             // pieces 0 .. 511 (or fewer)
-        if (wv < W2) DASR_GLDS16(src + 16 * SP_NTHR, dst + 1024 * SP_NWV);              // pieces 512 .. 767
+    // slices of K-step st (taps TPS st .. TPS st + TPS - 1) of chunk cc, slice fn0: SLAB bytes each at
+    // ((ns * 9 + tap) * NC + cc) * SLAB, into ring slot st % R
+    auto w_issue = [&](int cc, int st, int fn0) {
+#pragma unroll
+        for (int j = 0; j < TPS; ++j) {
+            const int tap = TPS * st + j;
+            const char* src = (const char*)a.ws + (size_t)(((fn0 / NTILE) * 9 + tap) * NC + cc) * SLAB + 16 * tid;
+            const dasr_lds_addr_t dst = ldsW + ((st % R) * TPS + j) * SLAB;
+            if (wv < W1) DASR_GLDS16(src, dst);                                             // pieces 0 .. 511 (or fewer)
+            if (wv < W2) DASR_GLDS16(src + 16 * SP_NTHR, dst + 1024 * SP_NWV);              // pieces 512 .. 767
+        }
     };
+    // halo pieces of the NEXT chunk issued in step st: all of them at least D - 1 = one whole step before that chunk's first
+    // step (whose wait lets the operations of the step before it stay in flight): one per step in steps 0 .. 4 of nine, three
+    // and two in steps 0 and 1 of three
+    auto halo_first = [](int st) { return TPS == 1 ? st : (st == 0 ? 0 : (st == 1 ? 3 : SP_NHP)); };
+    auto halo_count = [](int st) { return TPS == 1 ? (st < SP_NHP ? 1 : 0) : (st == 0 ? 3 : (st == 1 ? SP_NHP - 3 : 0)); };
 
     const int Pl = 2 * wv * SP_HW + li;
     const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4);
@@ -390,23 +403,25 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
             const int fcc = last ? 0 : cc + 1;
             const char* const hb = sH + par * SP_HBYTES;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                // the slice of this step (issued D steps ago) and this chunk's halo pieces have landed once all but the
-                // operations this wave issued in the last D - 1 steps (a halo piece in the steps of taps 0 .. 4, nwq slice
-                // pieces in every step) are done
+            for (int st = 0; st < NS; ++st) {
+                // the slices of this step (issued D steps ago) and this chunk's halo pieces have landed once all but the
+                // operations this wave issued in the last D - 1 steps (their halo pieces, TPS nwq slice pieces per step) are done
                 {
                     int nh = 0;
 #pragma unroll
-                    for (int k = 1; k < D; ++k) nh += ((tap - k + 9) % 9) < SP_NHP ? 1 : 0;
-                    sp_wait_vm_n(nh + (D - 1) * nwq);
+                    for (int k = 1; k < D; ++k) nh += halo_count((st - k + NS) % NS);
+                    sp_wait_vm_n(nh + (D - 1) * TPS * nwq);
                 }
                 DASR_RAW_BARRIER();
-                if (tap < SP_NHP) halo_issue(tap, fcc, par ^ 1);
-                if (tap + D < 9) w_issue(cc, tap + D, n0);
-                else             w_issue(fcc, tap + D - 9, last ? nn0 : n0);
-
+#pragma unroll
+                for (int u = 0; u < halo_count(st); ++u) halo_issue(halo_first(st) + u, fcc, par ^ 1);
+                if (st + D < NS) w_issue(cc, st + D, n0);
+                else             w_issue(fcc, st + D - NS, last ? nn0 : n0);
+#pragma unroll
+                for (int tj = 0; tj < TPS; ++tj) {
+                const int tap = TPS * st + tj;
                 const int dy = tap / 3, dx = tap - 3 * dy;
-                const char* const wb = sW + (tap % R) * SLAB + boff;
+                const char* const wb = sW + ((st % R) * TPS + tj) * SLAB + boff;
                 int Pq = Pl;
 #ifndef DASR_HIPEMU
                 asm volatile("" : "+v"(Pq));
@@ -431,6 +446,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
                     for (int m = 0; m < 2; ++m) acc[m][n] = F::mma(Bw, A[m], acc[m][n]);     // smallest terms first
                 }
                 DASR_SETPRIO(0);
+                }
             }
             par ^= 1;
         }
@@ -767,8 +783,10 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
     a.Q = (a.nitems + 7) / 8;
     a.G8 = a.Q < 32 ? a.Q : 32;
     if ((dasr_get_conv_bf16_impl() & 3) == 2) a.G8 = 1;        // tests: one workgroup per XCD walks every item of it
-    const size_t lds = 2 * (size_t)SP_HBYTES + (NT == 1 ? 2 * (size_t)(9 * NP * 32 * 32) : 3 * (size_t)(NP * 32 * NT * 32)) +
+    const size_t lds = 2 * (size_t)SP_HBYTES +
+                       (NT == 1 ? 2 * (size_t)(9 * NP * 32 * 32) : 3 * (size_t)((NP == 2 ? 3 : 1) * NP * 32 * NT * 32)) +
                        sizeof(float) * (size_t)(a.Cout + 32);
+    if (lds > 160 * 1024) return DASR_E_UNSUPPORTED;
     const dim3 grid(8 * a.G8);
     if (NT == 4)      DASR_LAUNCH((k_conv3x3_split<4, NP>), grid, dim3(SP_NTHR), lds, stream, a);
     else if (NT == 2) DASR_LAUNCH((k_conv3x3_split<2, NP>), grid, dim3(SP_NTHR), lds, stream, a);
