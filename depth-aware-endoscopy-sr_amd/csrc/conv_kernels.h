@@ -100,3 +100,13 @@ int conv9_bf16_fwd(const ConvGeom& g, const bf16_t* x, const float* w, const flo
 int conv9_bf16_dgrad(const ConvGeom& g, const float* dconv, const float* w, bf16_t* dx, int accumulate, void* stream);
 size_t conv9_bf16_wgrad_workspace(const ConvGeom& g);
 int conv9_bf16_wgrad(const ConvGeom& g, const bf16_t* x, const float* dconv, float* dw, void* workspace, void* stream);
+
+// conv9_split.hip (the 9x9 output convolution of the fp32 path as fp16 x 2 split products)
+bool conv9_split_supported(const ConvGeom& g);
+int conv9_split_fwd(const ConvGeom& g, const float* x, const float* xmax, const float* w, const float* wmax, const float* bias,
+                    float* y, void* stream);
+int conv9_split_dgrad(const ConvGeom& g, const float* dconv, const float* dmax, const float* w, const float* wmax, float* dx,
+                      int accumulate, void* stream);
+size_t conv9_split_wgrad_workspace(const ConvGeom& g);
+int conv9_split_wgrad(const ConvGeom& g, const float* x, const float* xmax, const float* dconv, const float* dmax, float* dw,
+                      void* workspace, void* stream);

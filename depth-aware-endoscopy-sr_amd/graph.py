@@ -43,6 +43,7 @@ SPLIT_PIECES = 2
 # ... and the kernels that PRODUCE those tensors (SEAN forward / backward, the mask layer, the split kernels' own epilogue, the
 # activation / PixelShuffle backward) leave max |.| behind themselves; False: one ops.absmax pass per operand (A/B, tests)
 FUSE_AMAX = True
+SPLIT_CONV9 = True              # ... and the 9x9 output convolution (csrc/conv9_split.hip)
 SPLIT_MIN_PIXELS = 1 << 14      # below this the launch is latency-bound either way
 WGRAD_STREAM = False   # measured: 167.7 -> 182.3 ms/step when on (contention between co-running MFMA kernels)
 _SIDE = {}
@@ -159,6 +160,10 @@ def bias_pair(tape, ba, bb):
     return out
 
 
+def _is_c9(w):
+    return isinstance(w.split, tuple) and isinstance(w.split[0], str)
+
+
 def _amax(var):
     """max |var.data| on the device for the fp16 x 2 split kernels: what the producing kernel left with the tensor
     (ops.set_amax: valid wherever the tensor is), else one ops.absmax pass, kept per tensor and stream (the forward
@@ -215,6 +220,14 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
         else:
             y = ops.conv3x3_fwd_split(x.data, w.split, bias.data if bias is not None else None, w.data.shape[4],
                                       residual.data if residual is not None else None, act, ps_r)
+    elif (SPLIT_BF16 and SPLIT_PIECES == 2 and SPLIT_CONV9 and f32 and w.data.dtype == torch.float32 and stride == 1 and pad == 4
+          and not transposed and tuple(w.data.shape[1:3]) == (9, 9) and act == ops.ACT_NONE and ps_r == 1 and residual is None
+          and x.data.shape[0] * x.data.shape[1] * x.data.shape[2] >= SPLIT_MIN_PIXELS
+          and ops.conv9_split_supported(x.data.shape[1], x.data.shape[2], w.data.shape[3], w.data.shape[4])):
+        # the 9x9 output convolution, same scheme (csrc/conv9_split.hip): the kernel is split when it is staged, only its max |.| is needed
+        if w.split is None:
+            w.split = ("c9", _folded(tape, ("c9max", "@%x" % w.data.data_ptr()), [w.data], lambda: ops.absmax(w.data[0])))
+        y = ops.conv9_fwd_split2(x.data, _amax(x), w.data, w.split[1], bias.data if bias is not None else None)
     else:
         # (the mask layer 1 -> 2C feeds the gamma_o|beta_o convolution, the encoder's first layer the head: their kernel
         # leaves max |y| behind)
@@ -264,7 +277,10 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             ws = _side_stream(dconv.device, "wgrad") if (WGRAD_STREAM and dconv.is_cuda) else None
             if ws is None and side_wgrad and TAIL_WGRAD_SIDE and SIDE_STREAM and dconv.is_cuda:
                 ws = _side_stream(dconv.device)       # the depth-branch stream: idle while the HR tail runs backward
-            if ws is None and w.split is not None and SPLIT_WGRAD:
+            if ws is None and _is_c9(w):
+                dmax = _amax_t(dconv)
+                dw, db = ops.conv9_wgrad_split2(x.data, _amax(x), dconv, dmax, want_bias=bias is not None)
+            elif ws is None and w.split is not None and SPLIT_WGRAD:
                 if isinstance(w.split, tuple):
                     dmax = _amax_t(dconv)
                     dw, db = ops.conv3x3_wgrad_split2(x.data, _amax(x), dconv, dmax, want_bias=bias is not None)
@@ -297,6 +313,10 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
                 x.grad = ops.conv2d_dgrad_act(dconv, w.data, x.data, x.epilogue[0], x.epilogue[1], stride, pad,
                                               transposed)
                 x.grad_is_preact = True
+            elif _is_c9(w):
+                if dmax is None:
+                    dmax = _amax_t(dconv)
+                x.grad = ops.conv9_dgrad_split2(dconv, dmax, w.data, w.split[1], x.data.shape, out=x.grad)
             elif isinstance(w.split, tuple):
                 if dmax is None:
                     dmax = _amax_t(dconv)

@@ -529,6 +529,41 @@ def conv3x3_dgrad_split2(dconv, dmax, ws, x_shape, out=None):
     return out
 
 
+# ---- the 9x9 output convolution in the same scheme (csrc/conv9_split.hip); w = the packed kernel (2,9,9,Cin,Cout) ------
+def conv9_split_supported(H, W, Cin, Cout):
+    return bool(_lib.get().dasr_conv9_split_supported(H, W, Cin, Cout))
+
+
+def conv9_fwd_split2(x, xmax, w, wmax, bias):
+    B, H, W, Cin = x.shape
+    Cout = w.shape[4]
+    y = empty((B, H, W, Cout), x)
+    _call("dasr_conv9_fwd_split2", _p(x), _p(xmax), _p(w), _p(wmax), _p(bias, True), _p(y), B, H, W, Cin, Cout)
+    return y
+
+
+def conv9_dgrad_split2(dconv, dmax, w, wmax, x_shape, out=None):
+    B, H, W, Cin = x_shape
+    Cout = dconv.shape[3]
+    acc = out is not None
+    if out is None:
+        out = empty(tuple(x_shape), dconv)
+    drop_amax(out)
+    _call("dasr_conv9_dgrad_split2", _p(dconv), _p(dmax), _p(w), _p(wmax), _p(out), 1 if acc else 0, B, H, W, Cin, Cout)
+    return out
+
+
+def conv9_wgrad_split2(x, xmax, dconv, dmax, want_bias=True):
+    B, H, W, Cin = x.shape
+    Cout = dconv.shape[3]
+    nbytes = int(_lib.get().dasr_conv9_wgrad_split2_workspace(B, H, W, Cin, Cout))
+    ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.float32, device=x.device)
+    dw = empty((9, 9, Cin, Cout), x)
+    db = empty((Cout,), x) if want_bias else None
+    _call("dasr_conv9_wgrad_split2", _p(x), _p(xmax), _p(dconv), _p(dmax), _p(dw), _p(db, True), _p(ws), nbytes, B, H, W, Cin, Cout)
+    return dw, db
+
+
 def conv2d_fwd_stats(x, w, bias):
     """3x3 / stride 1 / pad 1 conv (+bias) and the InstanceNorm statistics of its output: (y, mean[B,C], var[B,C])."""
     B, H, W, Cin = x.shape

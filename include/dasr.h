@@ -200,6 +200,19 @@ int dasr_conv3x3_wgrad_split2(const float* x, const float* xmax, const float* dc
                               float* dbias, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
                               void* stream);
 
+/* The 9x9 output convolution (conv_output, sftmd_arch.py:910,948: Cin % 32 == 0 -> Cout <= 3, pad 4) in the same fp16 x 2
+ * scheme (csrc/conv9_split.hip): fp32 x / w / y / dy / dx / dw, operands split into two scaled fp16 pieces when they are
+ * staged.  w_hwio = the packed kernel's plane 0 [9][9][Cin][Cout]; xmax / dmax / wmax: amax buffers (dasr_absmax) of x,
+ * dconv and w_hwio.  Replaces dasr_conv2d_fwd / _dgrad / _wgrad for that layer (same results to fp32 accuracy). */
+int dasr_conv9_split_supported(int H, int W, int Cin, int Cout);
+int dasr_conv9_fwd_split2(const float* x, const float* xmax, const float* w_hwio, const float* wmax, const float* bias, float* y,
+                          int B, int H, int W, int Cin, int Cout, void* stream);
+int dasr_conv9_dgrad_split2(const float* dconv, const float* dmax, const float* w_hwio, const float* wmax, float* dx,
+                            int accumulate, int B, int H, int W, int Cin, int Cout, void* stream);
+size_t dasr_conv9_wgrad_split2_workspace(int B, int H, int W, int Cin, int Cout);
+int dasr_conv9_wgrad_split2(const float* x, const float* xmax, const float* dconv, const float* dmax, float* dw_hwio, float* dbias,
+                            void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
+
 /* ---- instance-norm statistics ---------------------------------------------------------------
  * nn.InstanceNorm2d(affine=False) appears twice in a row on every DGB conv output
  * (sftmd_arch.py:811-820 then normalization.py:16-17,56).  Both collapse to one per-(b,c) scale:

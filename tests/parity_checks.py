@@ -1141,6 +1141,61 @@ def check_absmax(device, seed=3):
     return dict(ok=True)
 
 
+def check_conv9_split(device, seed=9):
+    """The 9x9 output convolution as fp16 x 2 split products (csrc/conv9_split.hip: forward, dgrad, accumulating dgrad,
+    wgrad + bias gradient) against torch's FLOAT64 convolution, next to the exact-fp32 MFMA kernels it replaces - the same
+    gates as check_split_conv (error <= 1.25x the fp32 kernel's + 1e-7 on the hardware, 3x + 2e-7 on the emulator, whose
+    MFMA model rounds per product).  Ragged tiles, two samples, Cout = 3 and 1, operands scaled far from 1, and - impl 2 -
+    three persistent workgroups walking long tile lists with the next tile's loads in flight."""
+    gen = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    fac, slack = (3.0, 2e-7) if device == "cpu" else (1.25, 1e-7)
+    out = {}
+    try:
+        for (B, H, W, cout, impl, sx_, sd_) in ((1, 11, 70, 3, 0, 1.0, 1.0), (2, 19, 60, 3, 0, 37.0, 2e-6), (2, 19, 60, 3, 2, 1.0, 1.0),
+                                               (1, 9, 33, 1, 2, 0.01, 5.0)):
+            ops.set_conv_bf16_impl(impl)
+            cin = 32
+            assert ops.conv9_split_supported(H, W, cin, cout) and not ops.conv9_split_supported(H, W, 64, cout)
+            x = rn(B, cin, H, W) * sx_
+            w = rn(cout, cin, 9, 9) * 0.02
+            bias = rn(cout) * 0.3 * sx_
+            dy = rn(B, cout, H, W) * sd_
+            x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+            ref = F.conv2d(x64, w64, bias.double(), padding=4)
+            gx64, gw64 = torch.autograd.grad(ref, (x64, w64), dy.double())
+            xd, dyd = nhwc(x).to(device), nhwc(dy).to(device)
+            wp = ops.pack_hwio(w.permute(2, 3, 1, 0).contiguous().to(device))
+            bd = bias.to(device)
+            wm, xm, dm = ops.absmax(wp[0]), ops.absmax(xd), ops.absmax(dyd)
+            y_sp = ops.conv9_fwd_split2(xd, xm, wp, wm, bd)
+            y_32 = ops.conv2d_fwd(xd, wp, bd, pad=4)
+            refd = ref.detach()
+            e_sp = (nchw(y_sp.cpu()).double() - refd).abs().max().item() / refd.abs().max().item()
+            e_32 = (nchw(y_32.cpu()).double() - refd).abs().max().item() / refd.abs().max().item()
+            assert e_sp <= fac * e_32 + slack, ("conv9 fwd", B, H, W, cout, e_sp, e_32)
+            dx_sp = ops.conv9_dgrad_split2(dyd, dm, wp, wm, xd.shape)
+            dx_32 = ops.conv2d_dgrad(dyd, wp, xd.shape, pad=4)
+            g_sp = (nchw(dx_sp.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
+            g_32 = (nchw(dx_32.cpu()).double() - gx64).abs().max().item() / gx64.abs().max().item()
+            assert g_sp <= fac * g_32 + slack, ("conv9 dgrad", B, H, W, cout, g_sp, g_32)
+            base = rn(B, H, W, cin) * sd_
+            accd = base.to(device).clone()
+            ops.conv9_dgrad_split2(dyd, dm, wp, wm, xd.shape, out=accd)
+            want = nhwc(gx64) + base.double()
+            g_acc = (accd.cpu().double() - want).abs().max().item() / want.abs().max().item()
+            assert g_acc <= fac * g_32 + 2 * slack, ("conv9 dgrad accumulate", g_acc, g_32)
+            dw_sp, db_sp = ops.conv9_wgrad_split2(xd, xm, dyd, dm)
+            dw_32, db_32 = ops.conv2d_wgrad(xd, dyd, (9, 9, cin, cout), pad=4)
+            w_sp, w_32 = rel_max(dw_sp.permute(3, 2, 0, 1), gw64), rel_max(dw_32.permute(3, 2, 0, 1), gw64)
+            assert w_sp <= fac * w_32 + slack, ("conv9 wgrad", B, H, W, cout, w_sp, w_32)
+            assert rel_max(db_sp, dy.double().sum((0, 2, 3))) <= 2 * rel_max(db_32, dy.double().sum((0, 2, 3))) + 1e-6
+            out["%dx%dx%d co%d impl%d" % (B, H, W, cout, impl)] = tuple(float("%.3g" % v) for v in (e_sp, e_32, g_sp, g_32, g_acc, w_sp, w_32))
+    finally:
+        ops.set_conv_bf16_impl(0)
+    return out
+
+
 def check_fused_amax(device, seed=11):
     """Every producer kernel that leaves max |.| of what it stores behind (the *_amax buffers of dasr.h) against torch's
     abs().max() of the tensor it wrote - EXACT (the kernels take maxima of the stored values themselves): SEAN forward

@@ -33,6 +33,10 @@ def test_split_conv(pieces):
     print(pc.check_split_conv("cuda", pieces=pieces))
 
 
+def test_conv9_split():
+    print(pc.check_conv9_split("cuda"))
+
+
 def test_absmax():
     print(pc.check_absmax("cuda"))
 

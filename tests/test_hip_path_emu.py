@@ -18,6 +18,10 @@ def test_split_conv(emu, pieces):
     print(pc.check_split_conv("cpu", pieces=pieces))
 
 
+def test_conv9_split(emu):
+    print(pc.check_conv9_split("cpu"))
+
+
 def test_absmax(emu):
     print(pc.check_absmax("cpu"))
 
