@@ -895,7 +895,10 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
     const int pair = wv % PAIRS, grp = wv / PAIRS;              // (wave-uniform: branches around MFMAs below)
     const int mt = pair / NTW, nt = pair % NTW;
     const int cgroups = a.Cout / COG;
-    const int ci0 = (blockIdx.x / cgroups) * CIG, co0 = (blockIdx.x % cgroups) * COG;
+    // (measured and dropped: an XCD-aware mapping that puts the gridDim.x (ci, co) blocks of one partial index - they read
+    // the same pixel tiles - on ONE XCD's L2: no change at 128 -> 128, 6 % slower at 64 -> 64; the kernel is not waiting for HBM)
+    const int bgrp = blockIdx.x, bpar = blockIdx.y;
+    const int ci0 = (bgrp / cgroups) * CIG, co0 = (bgrp % cgroups) * COG;
     const int tiles_x = (a.W + SW_TW - 1) / SW_TW, tiles_y = (a.H + TH - 1) / TH;
 
     f32x16 acc[9];
@@ -918,10 +921,10 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
     }
     if (a.zero) {
         const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
-        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
+        for (size_t i = ((size_t)bpar * gridDim.x + bgrp) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
     }
 
-    for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
+    for (int tile = bpar; tile < a.ntiles; tile += a.P) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int x0 = tx * SW_TW, y0 = ty * TH;
         // stage the tile: every global load of a thread before the first LDS write (see k_conv3x3_wgrad_mfma)
@@ -1051,8 +1054,8 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
             }
         }
     }
-    if (do_bias) a.bslabs[(size_t)blockIdx.y * a.Cout + co0 + tid] = bsum;
-    float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
+    if (do_bias) a.bslabs[(size_t)bpar * a.Cout + co0 + tid] = bsum;
+    float* slab = a.slabs + (size_t)bpar * 9 * a.Cin * a.Cout;
     if (grp != 0) return;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {

@@ -495,18 +495,30 @@ def check_constant_alpha_and_mask_resize(device):
 
 def check_batch_independence_and_determinism(device):
     """Instance norm is per sample: a frame's output must not depend on its batch mates; repeated runs are bitwise
-    identical in the forward (no atomics on the forward path)."""
+    identical in the forward (no atomics on the forward path).  Bitwise batch independence holds for the exact-fp32 kernels.
+    The split convolutions (graph.SPLIT_BF16) are chosen by launch size and, in the fp16 x 2 scheme, scale every tensor by a
+    power of two taken from the WHOLE batch's max |.|: a frame's low-order bits then depend on its batch mates (as they do
+    when a library picks its algorithm by batch size) - bounded here at a few fp32 roundings of a [0, 1] image."""
     case = dict(scale=8, which=[0, 1], L=16, nb=4, B=3, H=8, W=12)
     net, cfg = build_net(case, device)
     lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, 3, 8, 12, 8)]
-    with torch.no_grad():
-        full = net(lq, dm, mk)
-        again = net(lq, dm, mk)
-        solo = net(lq[1:2].contiguous(), dm[1:2].contiguous(), mk[1:2].contiguous())
-    assert torch.equal(full, again)
-    assert torch.equal(full[1:2], solo)
-    assert full.min().item() >= 0.0 and full.max().item() <= 1.0          # torch.clamp(out, 0, 1)
-    assert tuple(full.shape) == (3, 3, 64, 96)
+    old = graph.SPLIT_BF16, graph.SPLIT_MIN_PIXELS
+    try:
+        for split, min_px in ((False, old[1]), (True, old[1]), (True, 0)):
+            graph.SPLIT_BF16, graph.SPLIT_MIN_PIXELS = split, min_px
+            with torch.no_grad():
+                full = net(lq, dm, mk)
+                again = net(lq, dm, mk)
+                solo = net(lq[1:2].contiguous(), dm[1:2].contiguous(), mk[1:2].contiguous())
+            assert torch.equal(full, again)
+            if not split:
+                assert torch.equal(full[1:2], solo)
+            else:
+                assert (full[1:2] - solo).abs().max().item() <= 2e-5, (split, min_px, (full[1:2] - solo).abs().max().item())
+            assert full.min().item() >= 0.0 and full.max().item() <= 1.0          # torch.clamp(out, 0, 1)
+            assert tuple(full.shape) == (3, 3, 64, 96)
+    finally:
+        graph.SPLIT_BF16, graph.SPLIT_MIN_PIXELS = old
 
 
 def check_state_dict_roundtrip(device):
@@ -760,7 +772,8 @@ def check_checkpoint_interop(device, tmpdir):
 
 def check_x4_config_shape(device):
     """BASELINE.json configs[2] shape in fp32 (Kvasir x4, LR 256x320, DGBs 0..13, L=256; two frames): same
-    size-independent properties as check_large_frame_x2, plus batch independence (frame 1 alone == frame 1 of the pair)."""
+    size-independent properties as check_large_frame_x2, plus batch independence (frame 1 alone == frame 1 of the pair to a
+    few fp32 roundings of the [0, 1] image)."""
     from dasr_amd import harness
     net = DepthNet(which_ResBlk_depth=list(range(14)), in_nc=3, out_nc=3, nf=64, nb=16, scale=4, depth_latent_ch=256,
                    depthRangeNum=10)
@@ -776,7 +789,10 @@ def check_x4_config_shape(device):
         finally:
             graph.FORCE_GENERAL_SEAN = False
     assert tuple(fast.shape) == (2, 3, 1024, 1280)
-    assert torch.equal(fast[1:], single)
+    # (the fp16 x 2 split convolutions scale each tensor by a power of two taken from the whole batch's max |.|: a frame's
+    # low-order bits depend on its batch mates - check_batch_independence_and_determinism)
+    bd = (fast[1:] - single).abs().max().item()
+    assert bd <= 2e-5, bd
     diff = (fast - general).abs().max().item()
     psnr = O.psnr_255(fast.cpu(), general.cpu())
     assert diff <= 5e-4 and psnr > 90.0, (diff, psnr)
@@ -1006,6 +1022,18 @@ def check_data_parallel_gpu():
     case = dict(name="dp", scale=8, which=[0, 1], L=16, nb=4, B=4, H=8, W=12)
     net, cfg = build_net(case, "cuda")
     lq, gt, dm, mk = [t.cuda() for t in synth.closed_form_batch(0, 4, 8, 12, 8)]
+    # (what is checked is the replica protocol, bit for bit: on the exact-fp32 kernels - the split convolutions are chosen by
+    # launch size, which differs between the whole batch and its halves)
+    split_was = graph.SPLIT_BF16
+    graph.SPLIT_BF16 = False
+    try:
+        return _data_parallel_gpu_body(net, lq, gt, dm, mk)
+    finally:
+        graph.SPLIT_BF16 = split_was
+
+
+def _data_parallel_gpu_body(net, lq, gt, dm, mk):
+    from torch.nn.parallel import parallel_apply, replicate
     sr = net(lq, dm, mk)
     wgt = torch.cos(torch.arange(sr.numel(), dtype=torch.float32) * 0.013).reshape(sr.shape).cuda()
     (sr * wgt).sum().backward()

@@ -34,7 +34,8 @@ def test_bench_self_launches_two_ranks():
     assert out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and out["unit"] == "frames/s" and out["value"] > 0
     assert out["loss"] is not None and out["loss"] == out["loss"]
-    assert abs(out["value"] - 2 * 1 / (out["ms_per_step"] * 1e-3)) <= 1e-2 * out["value"]
+    # (value is printed with three decimals; on a loaded build container the emulated step takes tens of seconds)
+    assert abs(out["value"] - 2 * 1 / (out["ms_per_step"] * 1e-3)) <= 1e-2 * out["value"] + 1e-3
 
 
 def test_bench_single_rank_line_and_infer_mode():
