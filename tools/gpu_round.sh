@@ -25,5 +25,7 @@ timeout -k 10 200 python tools/bench_ops.py --batch 16 > $O/ops_b16.txt 2>&1; ec
 timeout -k 10 200 python tools/bench_ops.py --batch 32 --only sean,c1 > $O/ops_b32.txt 2>&1
 timeout -k 10 300 python tools/bench_ops_bf16.py > $O/ops_bf16_c3.txt 2>&1; echo "ops bf16 rc=$?"
 timeout -k 10 200 python tools/bench_ops_bf16.py --batch 16 --hw 128x160 > $O/ops_bf16_c4.txt 2>&1
-timeout -k 10 200 python tools/bench_split.py 16 > $O/ops_split_b16.txt 2>&1; timeout -k 10 200 python tools/bench_split.py 32 > $O/ops_split_b32.txt 2>&1
+timeout -k 10 300 python tools/bench_split.py 16 > $O/ops_split_b16.txt 2>&1; timeout -k 10 300 python tools/bench_split.py 32 > $O/ops_split_b32.txt 2>&1
+timeout -k 10 200 python tools/bench_conv9.py 16 > $O/ops_conv9_b16.txt 2>&1; timeout -k 10 200 python tools/bench_amax.py > $O/ops_amax_b16.txt 2>&1
+timeout -k 10 300 python bench.py --split-pieces 3 --no-cpu-baseline --no-b32 > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err; echo "bench bf16x3 rc=$?"; cut -c1-200 $O/bench_bf16x3.json
 ls $O
