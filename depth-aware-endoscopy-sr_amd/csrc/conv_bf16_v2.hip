@@ -475,7 +475,7 @@ extern "C" int dasr_set_conv_bf16_impl(int impl) {
 #ifndef DASR_V2_DEBUG
     if (dbg != 0) return DASR_E_UNSUPPORTED;
 #endif
-    if (impl < 0 || (impl & 3) > 2 || (impl >> 4) > 2 || (impl & 12)) return DASR_E_UNSUPPORTED;
+    if (impl < 0 || (impl & 3) > 2 || ((impl >> 4) & 3) > 2 || (impl & 12) || (impl >> 8)) return DASR_E_UNSUPPORTED;   // (+ 64 / + 128: see sw_launch, conv_split_bf16.hip)
     g_conv_bf16_impl = impl;
     g_conv_bf16_dbg = dbg;
     return DASR_OK;

@@ -1067,6 +1067,210 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
     }
 }
 
+// ---- the weight gradient of the fp16 x 2 scheme, operands split ONCE when the tile is staged (round 3, second version).
+// In k_conv3x3_wgrad_split<.., 2> every K-step splits its 38 fp32 values in registers: ~160 VALU beside 27 MFMAs, and the two
+// waves that share an x (or dconv) block each split it again - as long as the matrix work, 0.69 PF.  Here the staging pass
+// (global -> registers -> LDS, which exists anyway) writes TWO fp16 planes [pixel][channel] (pixel stride 64 bytes mod 128),
+// and the K loop is the one of k_conv3x3_wgrad_bf16 (conv_bf16_mfma.hip) on them: operands come out of LDS as MFMA
+// fragments through ds_read_b64_tr_b16 (K = pixels: the transpose of the staged layout), the three taps of a kernel row
+// share ONE 12-pixel read per plane (dx = 0: dwords 0..3, dx = 2: dwords 1..4, dx = 1: v_alignbit of neighbours): per K-step
+// 22 transposed reads + 24 VALU + 27 MFMAs.  The bias gradient is summed from the staging registers (exact fp32 values).
+__host__ __device__ constexpr int sw2_stride(int ch) { return ch == 32 ? 32 : ch + 32; }    // fp16 elements per pixel and plane
+__device__ __forceinline__ s16x4 sp_tr16(const f16_t* p) {
+    const bf16x4 r = lds_read_tr16((const bf16_t*)p);
+    s16x4 v;
+    __builtin_memcpy(&v, &r, 8);
+    return v;
+}
+template <int MT, int NTW>
+__global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split2(SplitWgradArgs a) {
+    DASR_DYN_SMEM(smem);
+    constexpr int CIG = 32 * MT, COG = 32 * NTW, TH = sw_th(MT, NTW), HW = SW_TW + 2;
+    constexpr int PAIRS = MT * NTW, G = 4 / PAIRS;
+    constexpr int SXP = sw2_stride(CIG), SDP = sw2_stride(COG);
+    constexpr int NXE = (TH + 2) * HW * SXP, NDE = TH * SW_TW * SDP;
+    f16_t* sX0 = (f16_t*)smem;                                  // [(TH+2)*HW][SXP]: fp16(x s)
+    f16_t* sX1 = sX0 + NXE;                                     //                    what that rounding left
+    f16_t* sD0 = sX1 + NXE;                                     // [TH*TW][SDP]
+    f16_t* sD1 = sD0 + NDE;
+    const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
+    const int li = lane & 31, lh = lane >> 5;
+    const int pair = wv % PAIRS, grp = wv / PAIRS;              // (wave-uniform: branches around MFMAs below)
+    const int mt = pair / NTW, nt = pair % NTW;
+    const int cgroups = a.Cout / COG;
+    const int ci0 = (blockIdx.x / cgroups) * CIG, co0 = (blockIdx.x % cgroups) * COG;
+    const int tiles_x = (a.W + SW_TW - 1) / SW_TW, tiles_y = (a.H + TH - 1) / TH;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool do_bias = a.bslabs != nullptr && ci0 == 0;       // (workgroup-uniform)
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);                // this thread's channel quad (tid % (COG / 4)) of sum dconv
+    float sx, sd, inv;
+    {
+        __shared__ float s_red[32];
+        sp_scales_gather<2>(a.xmax, a.dmax, s_red);
+        __syncthreads();
+        float mx = s_red[0], md = s_red[16];
+        for (int w = 1; w < 4; ++w) { mx = fmaxf(mx, s_red[w]); md = fmaxf(md, s_red[16 + w]); }
+        const int kx = sp_scale_exp(mx), kd = sp_scale_exp(md);
+        sx = sp_pow2(kx); sd = sp_pow2(kd); inv = sp_pow2(-(kx + kd));
+    }
+    if (a.zero) {
+        const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
+        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
+    }
+    // transposed-read lane roles: lane 4q+p of its 16-lane group passes the address of pixel row q, channels 4p..4p+3 of the
+    // group's 16 channels; groups 0,1 cover channels 0..15 / 16..31 of pixels 0..7 of the K-step, groups 2,3 pixels 8..15
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    const int xoff = 32 * mt + 16 * tg + 4 * tp, doff = 32 * nt + 16 * tg + 4 * tp;
+    // four values times the tensor's scale -> 4 + 4 fp16 (one 8-byte LDS write per plane)
+    auto put = [&](f16_t* p0, f16_t* p1, int off, float4 v, float s) {
+        const float f[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+        f16_t h0[4], h1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h0[j] = (f16_t)f[j];
+            h1[j] = (f16_t)(f[j] - (float)h0[j]);
+        }
+        __builtin_memcpy(p0 + off, h0, 8);
+        __builtin_memcpy(p1 + off, h1, 8);
+    };
+
+    for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx * SW_TW, y0 = ty * TH;
+        // stage the tile: every global load of a thread before the first LDS write (see k_conv3x3_wgrad_mfma)
+        constexpr int NX = (TH + 2) * HW * (CIG / 4), NXI = (NX + 255) / 256;        // 64 x 64 block: 2176 float4 pieces, 9 per thread
+        constexpr int ND = TH * SW_TW * (COG / 4), NDI = (ND + 255) / 256;           //                1024: 4 per thread
+        // (144 accumulator registers are resident: the x pieces go in two batches, the second one after the barrier)
+        constexpr int XA = NDI >= 8 ? 1 : (8 - NDI < NXI ? 8 - NDI : NXI);
+        float4 vx[NXI - XA > XA ? NXI - XA : XA], vd[NDI];
+        auto ldx = [&](int u) {
+            const int idx = tid + 256 * u;
+            const int c4 = idx % (CIG / 4), pix = idx / (CIG / 4);
+            const int gy = y0 + pix / HW - 1, gx = x0 + pix % HW - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
+            return v;
+        };
+        auto stx = [&](int u, float4 v) {
+            const int idx = tid + 256 * u;
+            if (idx < NX) put(sX0, sX1, (idx / (CIG / 4)) * SXP + 4 * (idx % (CIG / 4)), v, sx);
+        };
+#pragma unroll
+        for (int u = 0; u < XA; ++u) vx[u] = ldx(u);
+#pragma unroll
+        for (int u = 0; u < NDI; ++u) {
+            const int idx = tid + 256 * u;
+            const int c4 = idx % (COG / 4), pix = idx / (COG / 4);
+            const int gy = y0 + pix / SW_TW, gx = x0 + pix % SW_TW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < ND && gy < a.H && gx < a.W)
+                v = *(const float4*)(a.dy + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * c4);
+            vd[u] = v;
+        }
+        __syncthreads();                        // every wave is done with the previous tile
+#pragma unroll
+        for (int u = 0; u < XA; ++u) stx(u, vx[u]);
+#pragma unroll
+        for (int u = 0; u < NDI; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < ND) put(sD0, sD1, (idx / (COG / 4)) * SDP + 4 * (idx % (COG / 4)), vd[u], sd);
+            if (do_bias) { bs.x += vd[u].x; bs.y += vd[u].y; bs.z += vd[u].z; bs.w += vd[u].w; }   // (zeros outside the image)
+        }
+#pragma unroll
+        for (int u = XA; u < NXI; ++u) vx[u - XA] = ldx(u);
+#pragma unroll
+        for (int u = XA; u < NXI; ++u) stx(u, vx[u - XA]);
+        __syncthreads();
+        // K-step s = 16 consecutive pixels of one tile row.  EXEC is all ones here (the tile loop and the K-step split are
+        // wave-uniform), as ds_read_b64_tr_b16 requires.
+        constexpr int NS = TH * (SW_TW / 16);
+#pragma unroll 1
+        for (int s = grp; s < NS; s += G) {
+            const int py = s / (SW_TW / 16), px0 = 16 * (s % (SW_TW / 16)) + 8 * lh + tq;
+            f16x8 Bd[2];
+            {
+                const int o = (py * SW_TW + px0) * SDP + doff;
+                const s16x4 l0 = sp_tr16(sD0 + o), u0 = sp_tr16(sD0 + o + 4 * SDP);
+                const s16x4 l1 = sp_tr16(sD1 + o), u1 = sp_tr16(sD1 + o + 4 * SDP);
+                __builtin_memcpy(&Bd[0], &l0, 8); __builtin_memcpy((char*)&Bd[0] + 8, &u0, 8);
+                __builtin_memcpy(&Bd[1], &l1, 8); __builtin_memcpy((char*)&Bd[1] + 8, &u1, 8);
+            }
+            const int xo = (py * HW + px0) * SXP + xoff;
+            // (pixels 10, 11 of the last window of a tile row belong to the next row / lie past the tile: read, unused)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                f16x8 A[3][2];                                  // [dx][plane]
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const f16_t* ap = (pl == 0 ? sX0 : sX1) + xo + dy * HW * SXP;
+                    const s16x4 a0 = sp_tr16(ap), a1 = sp_tr16(ap + 4 * SXP), a2 = sp_tr16(ap + 8 * SXP);
+                    unsigned R[6];
+                    __builtin_memcpy(&R[0], &a0, 8);
+                    __builtin_memcpy(&R[2], &a1, 8);
+                    __builtin_memcpy(&R[4], &a2, 8);
+                    const unsigned V0[4] = {R[0], R[1], R[2], R[3]}, V2[4] = {R[1], R[2], R[3], R[4]};
+                    unsigned V1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) V1[e] = (R[e] >> 16) | (R[e + 1] << 16);
+                    __builtin_memcpy(&A[0][pl], V0, 16);
+                    __builtin_memcpy(&A[1][pl], V1, 16);
+                    __builtin_memcpy(&A[2][pl], V2, 16);
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[3 * dy + dx] = SpFrag<2>::mma(A[dx], Bd, acc[3 * dy + dx]);
+            }
+        }
+    }
+    float* sR = (float*)smem;
+    if (G > 1) {
+        // waves grp = 1 .. G-1 hand their accumulators to wave grp = 0 of the same pair, one tap at a time through
+        // (G - 1) * PAIRS * 4 KB of the (now idle) staging LDS
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            __syncthreads();
+            if (grp > 0) {
+                float* q = sR + ((grp - 1) * PAIRS + pair) * 1024 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q[64 * r] = acc[t][r];
+            }
+            __syncthreads();
+            if (grp == 0) {
+                for (int gg = 0; gg < G - 1; ++gg) {
+                    const float* q = sR + (gg * PAIRS + pair) * 1024 + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += q[64 * r];
+                }
+            }
+        }
+    }
+    if (do_bias) {                              // the threads' channel-quad sums meet through LDS: threads q, q + COG/4, ... own quad q
+        __syncthreads();
+        *(float4*)(sR + 4 * tid) = bs;
+        __syncthreads();
+        if (tid < COG) {
+            float r = 0.f;
+            for (int t = tid >> 2; t < 256; t += COG / 4) r += sR[4 * t + (tid & 3)];
+            a.bslabs[(size_t)blockIdx.y * a.Cout + co0 + tid] = r;
+        }
+    }
+    float* slab = a.slabs + (size_t)blockIdx.y * 9 * a.Cin * a.Cout;
+    if (grp != 0) return;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[((size_t)tap * a.Cin + ci) * a.Cout + co0 + 32 * nt + li] = acc[tap][r] * inv;
+        }
+    }
+}
+
 static void sw_plan(int B, int H, int W, int Cin, int Cout, int& MT, int& NTW, int& groups, int& ntiles, int& P) {
     MT = (Cin % 64) == 0 ? 2 : 1;
     NTW = (Cout % 64) == 0 ? 2 : 1;
@@ -1102,8 +1306,23 @@ static int sw_launch(const float* x, const float* xmax, const float* dconv, cons
     while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
     SplitWgradArgs a{xmax, dmax, x, dconv, slabs, bslabs, ysplit > 1 ? dw : nullptr, ysplit > 1 ? nW : 0, B, H, W, Cin, Cout, P, ntiles};
     const int th = sw_th(MT, NTW);
-    const size_t lds = sizeof(float) * (size_t)((th + 2) * (SW_TW + 2) * 32 * MT + th * SW_TW * 32 * NTW);
     const dim3 grid(groups, P);
+    // fp16 x 2: blocks of four (ci, co) pairs take the staged-split kernel (128 -> 128 424 -> 347 us, 64 -> 64 134 -> 115, 32 -> 128
+    // at 512 x 640 1716 -> 1433); the smaller blocks keep the first version - their taller tiles in two padded fp16 planes
+    // leave room for one workgroup per CU only (64 -> 32: 258 -> 327 us, 32 -> 32: 517 -> 556).  impl + 64 (A/B, tests): the
+    // first version everywhere; impl + 128: the staged-split kernel everywhere.
+    const int impl = dasr_get_conv_bf16_impl();
+    if (NP == 2 && (impl & 64) == 0 && (MT * NTW == 4 || (impl & 128) != 0)) {
+        size_t lds2 = sizeof(f16_t) * 2 * (size_t)((th + 2) * (SW_TW + 2) * sw2_stride(32 * MT) + th * SW_TW * sw2_stride(32 * NTW));
+        if (lds2 < 4 * 4096) lds2 = 4 * 4096;                     // (the bias-gradient exchange: 256 float4)
+        if (MT == 2 && NTW == 2)      DASR_LAUNCH((k_conv3x3_wgrad_split2<2, 2>), grid, dim3(256), lds2, stream, a);
+        else if (MT == 1 && NTW == 4) DASR_LAUNCH((k_conv3x3_wgrad_split2<1, 4>), grid, dim3(256), lds2, stream, a);
+        else if (MT == 2 && NTW == 1) DASR_LAUNCH((k_conv3x3_wgrad_split2<2, 1>), grid, dim3(256), lds2, stream, a);
+        else if (MT == 1 && NTW == 2) DASR_LAUNCH((k_conv3x3_wgrad_split2<1, 2>), grid, dim3(256), lds2, stream, a);
+        else                          DASR_LAUNCH((k_conv3x3_wgrad_split2<1, 1>), grid, dim3(256), lds2, stream, a);
+        return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit > 1, bslabs, dbias, Cout);
+    }
+    const size_t lds = sizeof(float) * (size_t)((th + 2) * (SW_TW + 2) * 32 * MT + th * SW_TW * 32 * NTW);
     if (MT == 2 && NTW == 2)      DASR_LAUNCH((k_conv3x3_wgrad_split<2, 2, NP>), grid, dim3(256), lds, stream, a);
     else if (MT == 1 && NTW == 4) DASR_LAUNCH((k_conv3x3_wgrad_split<1, 4, NP>), grid, dim3(256), lds, stream, a);
     else if (MT == 2 && NTW == 1) DASR_LAUNCH((k_conv3x3_wgrad_split<2, 1, NP>), grid, dim3(256), lds, stream, a);
