@@ -187,6 +187,36 @@ __device__ __forceinline__ SpScale sp_scales_take(const float* s_red) {
     return r;
 }
 
+// ---- NP = 2: the landed fp32 halo chunk is split ONCE, in place.  A tap's fragment used to be read as fp32 and split in
+// registers by the wave that needed it - every halo value up to nine times (once per tap), 48 VALU per tap and wave beside
+// 24 / 12 / 6 MFMAs (NT = 4 / 2 / 1).  Now each thread rewrites the five 16-byte pieces it fetched (piece s of pixel P holds
+// channels 4 (s ^ key), key = (P >> 2) & 3) as fp16: slot (2 plane + khalf) ^ key of the pixel's 64 bytes = channels
+// 8 khalf .. + 7 of plane 0 (fp16(x s)) or plane 1 (what that rounding left) - a tap's fragment is then ONE ds_read_b128
+// with the same swizzle, no arithmetic.  All pieces are read before any is written (the new slots overlap other threads' old
+// ones): two LDS barriers per chunk, ~100 VALU per thread and chunk instead of ~430.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sp_presplit(char* hb, float sx, int tid) {
+    float4 raw[SP_NHP];
+#pragma unroll
+    for (int u = 0; u < SP_NHP; ++u) raw[u] = *(const float4*)(hb + 1024 * SP_NWV * u + 16 * tid);
+    DASR_LDS_BARRIER();
+#pragma unroll
+    for (int u = 0; u < SP_NHP; ++u) {
+        const int P = (tid >> 2) + (SP_NTHR / 4) * u, key = (P >> 2) & 3, c4 = (tid & 3) ^ key;
+        const float f[4] = {raw[u].x * sx, raw[u].y * sx, raw[u].z * sx, raw[u].w * sx};
+        f16x4 h0, h1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h0[j] = (f16_t)f[j];
+            h1[j] = (f16_t)(f[j] - (float)h0[j]);
+        }
+        char* const px = hb + P * 64 + 8 * (c4 & 1);
+        *(f16x4*)(px + (((c4 >> 1) ^ key) << 4)) = h0;
+        *(f16x4*)(px + (((2 + (c4 >> 1)) ^ key) << 4)) = h1;
+    }
+    DASR_LDS_BARRIER();
+}
+
 // ---- epilogue of one item: 32 channels per pass through [pixel][32 + 4] fp32 of the wave's scratch, 32 bytes per lane out;
 // residual, activation, accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue.  NP = 2: the sums are in
 // scaled units - times inv (the exact inverse of the two scales), plus the bias.
@@ -417,6 +447,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
                 for (int u = 0; u < halo_count(st); ++u) halo_issue(halo_first(st) + u, fcc, par ^ 1);
                 if (st + D < NS) w_issue(cc, st + D, n0);
                 else             w_issue(fcc, st + D - NS, last ? nn0 : n0);
+                if (NP == 2 && st == 0) sp_presplit(sH + par * SP_HBYTES, sc.sx, tid);    // (this chunk's halo: landed, see the wait above)
 #pragma unroll
                 for (int tj = 0; tj < TPS; ++tj) {
                 const int tap = TPS * st + tj;
@@ -431,10 +462,15 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
                 for (int m = 0; m < 2; ++m) {
                     const int P = Pq + (m + dy) * SP_HW + dx;
                     const int key = (P >> 2) & 3;
-                    const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
-                    const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
-                    const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    F::split(xv, sc.sx, A[m]);
+                    if constexpr (NP == 2) {            // pre-split planes (sp_presplit): one 16-byte read per plane
+                        A[m][0] = *(const typename F::type*)(hb + P * 64 + ((lh ^ key) << 4));
+                        A[m][1] = *(const typename F::type*)(hb + P * 64 + (((2 + lh) ^ key) << 4));
+                    } else {
+                        const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
+                        const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
+                        const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        F::split(xv, sc.sx, A[m]);
+                    }
                 }
                 DASR_SETPRIO(1);
 #pragma unroll
@@ -585,6 +621,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
             sp_wait_vm<0>();
             DASR_RAW_BARRIER();
             chunk_issue(last ? 0 : cc + 1, last ? nn0 : n0, par ^ 1);
+            if (NP == 2) sp_presplit(sH + par * SP_HBYTES, sc.sx, tid);
             const char* const hb = sH + par * SP_HBYTES;
             const char* const wc = sW + par * WCH + boff;
 #pragma unroll
@@ -599,10 +636,15 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
                 for (int m = 0; m < 2; ++m) {
                     const int P = Pq + (m + dy) * SP_HW + dx;
                     const int key = (P >> 2) & 3;
-                    const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
-                    const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
-                    const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    F::split(xv, sc.sx, A[m]);
+                    if constexpr (NP == 2) {            // pre-split planes (sp_presplit): one 16-byte read per plane
+                        A[m][0] = *(const typename F::type*)(hb + P * 64 + ((lh ^ key) << 4));
+                        A[m][1] = *(const typename F::type*)(hb + P * 64 + (((2 + lh) ^ key) << 4));
+                    } else {
+                        const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
+                        const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
+                        const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        F::split(xv, sc.sx, A[m]);
+                    }
                 }
                 const char* const wb = wc + tap * SLAB;
                 typename F::type Bw[NP];

@@ -23,6 +23,7 @@ typedef char* dasr_lds_addr_t;
 #define DASR_GLDS16(gsrc, lds_base) memcpy((lds_base) + 16 * hipemu::lane_id(), (const void*)(gsrc), 16)
 #define DASR_WAIT_VM(n) ((void)0)
 #define DASR_RAW_BARRIER() hipemu::block_barrier()
+#define DASR_LDS_BARRIER() hipemu::block_barrier()
 #define DASR_SETPRIO(n) ((void)0)
 #define DASR_SCHED_GROUP(mask, n) ((void)0)
 #define DASR_DEVICE_CONST static const
@@ -57,6 +58,9 @@ __device__ __forceinline__ void dasr_glds16(const void* gsrc, unsigned lds_base_
 #define DASR_GLDS16(gsrc, lds_base) dasr_glds16((const void*)(gsrc), __builtin_amdgcn_readfirstlane(lds_base))
 #define DASR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define DASR_RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+// the same after this wave's LDS operations have completed (LDS written by one wave, read by another) - and nothing else:
+// __syncthreads() would also drain vmcnt, i.e. the LDS-DMA prefetches the kernel keeps in flight on purpose
+#define DASR_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define DASR_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // scheduling hint: the next n instructions of the masked kind (0x8 MFMA, 0x100 LDS read, 0x2 VALU) go here, in this order
 #define DASR_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
