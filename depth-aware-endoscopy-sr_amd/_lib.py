@@ -99,10 +99,16 @@ def reset_for_tests():
 
 
 def stream():
-    """Current HIP stream of the caller's device as an integer handle (0 for the emulator)."""
-    if not is_device_build():
+    """Current HIP stream of the caller's device as an integer handle (0 for the emulator).  (The raw-stream query: a step
+    issues ~2000 kernels from Python and torch.cuda.current_stream() builds a Stream object every time.)"""
+    if _is_device is None:
+        get()
+    if not _is_device:
         return 0
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(torch.cuda.current_device())
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda dev: torch.cuda.current_stream(dev).cuda_stream)
 
 
 def ptr(t, allow_none=False, dtype=torch.float32):
@@ -115,9 +121,11 @@ def ptr(t, allow_none=False, dtype=torch.float32):
         raise TypeError("dasr_amd: expected %s, got %s" % (dtype, t.dtype))
     if not t.is_contiguous():
         raise ValueError("dasr_amd: tensor must be contiguous")
-    if is_device_build() != t.is_cuda:
+    if _is_device is None:
+        get()
+    if _is_device != t.is_cuda:
         raise RuntimeError("dasr_amd: tensor on %s but library is a %s build"
-                           % (t.device, "device" if is_device_build() else "CPU-emulator"))
+                           % (t.device, "device" if _is_device else "CPU-emulator"))
     return t.data_ptr()
 
 
