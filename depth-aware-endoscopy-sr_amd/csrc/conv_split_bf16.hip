@@ -189,32 +189,40 @@ __device__ __forceinline__ SpScale sp_scales_take(const float* s_red) {
 
 // ---- NP = 2: the landed fp32 halo chunk is split ONCE, in place.  A tap's fragment used to be read as fp32 and split in
 // registers by the wave that needed it - every halo value up to nine times (once per tap), 48 VALU per tap and wave beside
-// 24 / 12 / 6 MFMAs (NT = 4 / 2 / 1).  Now each thread rewrites the five 16-byte pieces it fetched (piece s of pixel P holds
-// channels 4 (s ^ key), key = (P >> 2) & 3) as fp16: slot (2 plane + khalf) ^ key of the pixel's 64 bytes = channels
-// 8 khalf .. + 7 of plane 0 (fp16(x s)) or plane 1 (what that rounding left) - a tap's fragment is then ONE ds_read_b128
-// with the same swizzle, no arithmetic.  All pieces are read before any is written (the new slots overlap other threads' old
-// ones): two LDS barriers per chunk, ~100 VALU per thread and chunk instead of ~430.
+// 24 / 12 / 6 MFMAs (NT = 4 / 2 / 1).  Now each thread rewrites the five 16-byte pieces IT fetched (piece s of pixel P holds
+// the channel quad c4 = s ^ key, key = (P >> 2) & 3) as [fp16(x s) of the four channels | what that rounding left]: nobody
+// else touches those bytes, and the thread's own counted wait says they have landed - so the conversion sits between the
+// chunk's wait and the barrier it had anyway (with an lgkmcnt(0) in front: the barrier now also publishes LDS writes).  A
+// fragment (plane pl, channels 8 lh .. + 7) is two ds_read_b64: bytes 8 pl of the pieces (2 lh) ^ key and (2 lh + 1) ^ key.
+// ~100 VALU per thread and chunk instead of ~430.  (First form of this: fp16 planes in 16-byte slots - one ds_read_b128 per
+// fragment, but all pieces had to be read before any was written: two more barriers per chunk.  Same speed on every shape,
+// A/B on one MI355X; this form has nothing to synchronise.)
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void sp_presplit(char* hb, float sx, int tid) {
     float4 raw[SP_NHP];
 #pragma unroll
     for (int u = 0; u < SP_NHP; ++u) raw[u] = *(const float4*)(hb + 1024 * SP_NWV * u + 16 * tid);
-    DASR_LDS_BARRIER();
 #pragma unroll
     for (int u = 0; u < SP_NHP; ++u) {
-        const int P = (tid >> 2) + (SP_NTHR / 4) * u, key = (P >> 2) & 3, c4 = (tid & 3) ^ key;
         const float f[4] = {raw[u].x * sx, raw[u].y * sx, raw[u].z * sx, raw[u].w * sx};
-        f16x4 h0, h1;
+        f16x8 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            h0[j] = (f16_t)f[j];
-            h1[j] = (f16_t)(f[j] - (float)h0[j]);
+            const f16_t h0 = (f16_t)f[j];
+            o[j] = h0;
+            o[4 + j] = (f16_t)(f[j] - (float)h0);
         }
-        char* const px = hb + P * 64 + 8 * (c4 & 1);
-        *(f16x4*)(px + (((c4 >> 1) ^ key) << 4)) = h0;
-        *(f16x4*)(px + (((2 + (c4 >> 1)) ^ key) << 4)) = h1;
+        *(f16x8*)(hb + 1024 * SP_NWV * u + 16 * tid) = o;
     }
-    DASR_LDS_BARRIER();
+}
+// fragment of plane pl for the lane's K-half lh at pixel P (byte address hb + 64 P)
+__device__ __forceinline__ f16x8 sp_frag(const char* px, int lh, int key, int pl) {
+    const f16x4 lo = *(const f16x4*)(px + ((((2 * lh) ^ key)) << 4) + 8 * pl);
+    const f16x4 hi = *(const f16x4*)(px + ((((2 * lh + 1) ^ key)) << 4) + 8 * pl);
+    f16x8 r;
+    __builtin_memcpy(&r, &lo, 8);
+    __builtin_memcpy((char*)&r + 8, &hi, 8);
+    return r;
 }
 
 // ---- epilogue of one item: 32 channels per pass through [pixel][32 + 4] fp32 of the wave's scratch, 32 bytes per lane out;
@@ -442,12 +450,16 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
                     for (int k = 1; k < D; ++k) nh += halo_count((st - k + NS) % NS);
                     sp_wait_vm_n(nh + (D - 1) * TPS * nwq);
                 }
-                DASR_RAW_BARRIER();
+                if (NP == 2 && st == 0) {              // this chunk's halo pieces - this thread's own - have landed: split them
+                    sp_presplit(sH + par * SP_HBYTES, sc.sx, tid);
+                    DASR_LDS_BARRIER();
+                } else {
+                    DASR_RAW_BARRIER();
+                }
 #pragma unroll
                 for (int u = 0; u < halo_count(st); ++u) halo_issue(halo_first(st) + u, fcc, par ^ 1);
                 if (st + D < NS) w_issue(cc, st + D, n0);
                 else             w_issue(fcc, st + D - NS, last ? nn0 : n0);
-                if (NP == 2 && st == 0) sp_presplit(sH + par * SP_HBYTES, sc.sx, tid);    // (this chunk's halo: landed, see the wait above)
 #pragma unroll
                 for (int tj = 0; tj < TPS; ++tj) {
                 const int tap = TPS * st + tj;
@@ -462,9 +474,9 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
                 for (int m = 0; m < 2; ++m) {
                     const int P = Pq + (m + dy) * SP_HW + dx;
                     const int key = (P >> 2) & 3;
-                    if constexpr (NP == 2) {            // pre-split planes (sp_presplit): one 16-byte read per plane
-                        A[m][0] = *(const typename F::type*)(hb + P * 64 + ((lh ^ key) << 4));
-                        A[m][1] = *(const typename F::type*)(hb + P * 64 + (((2 + lh) ^ key) << 4));
+                    if constexpr (NP == 2) {            // pre-split pieces (sp_presplit)
+                        A[m][0] = sp_frag(hb + P * 64, lh, key, 0);
+                        A[m][1] = sp_frag(hb + P * 64, lh, key, 1);
                     } else {
                         const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
                         const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
@@ -619,9 +631,13 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
             // this chunk's halo and slices were issued a whole chunk ago (or in the prologue): everything this wave has in
             // flight is exactly that (plus the previous item's output stores)
             sp_wait_vm<0>();
-            DASR_RAW_BARRIER();
+            if (NP == 2) {
+                sp_presplit(sH + par * SP_HBYTES, sc.sx, tid);
+                DASR_LDS_BARRIER();
+            } else {
+                DASR_RAW_BARRIER();
+            }
             chunk_issue(last ? 0 : cc + 1, last ? nn0 : n0, par ^ 1);
-            if (NP == 2) sp_presplit(sH + par * SP_HBYTES, sc.sx, tid);
             const char* const hb = sH + par * SP_HBYTES;
             const char* const wc = sW + par * WCH + boff;
 #pragma unroll
@@ -636,9 +652,9 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
                 for (int m = 0; m < 2; ++m) {
                     const int P = Pq + (m + dy) * SP_HW + dx;
                     const int key = (P >> 2) & 3;
-                    if constexpr (NP == 2) {            // pre-split planes (sp_presplit): one 16-byte read per plane
-                        A[m][0] = *(const typename F::type*)(hb + P * 64 + ((lh ^ key) << 4));
-                        A[m][1] = *(const typename F::type*)(hb + P * 64 + (((2 + lh) ^ key) << 4));
+                    if constexpr (NP == 2) {            // pre-split pieces (sp_presplit)
+                        A[m][0] = sp_frag(hb + P * 64, lh, key, 0);
+                        A[m][1] = sp_frag(hb + P * 64, lh, key, 1);
                     } else {
                         const float4 lo = *(const float4*)(hb + P * 64 + (((2 * lh) ^ key) << 4));
                         const float4 hi = *(const float4*)(hb + P * 64 + (((2 * lh + 1) ^ key) << 4));
