@@ -1206,13 +1206,18 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split2(SplitWgradArgs 
         // (144 accumulator registers are resident: the x pieces go in two batches, the second one after the barrier)
         constexpr int XA = NDI >= 8 ? 1 : (8 - NDI < NXI ? 8 - NDI : NXI);
         float4 vx[NXI - XA > XA ? NXI - XA : XA], vd[NDI];
+        // (buffer loads: a 32-bit offset per piece, the zero padding from the descriptor's range check - SQ counters of the
+        // first form, with 64-bit predicated loads: 6.9 VALU per MFMA, most of them this staging pass)
+        const BufRsrc rx = dasr_make_rsrc(a.x + (size_t)b * a.H * a.W * a.Cin, (size_t)a.H * a.W * a.Cin * sizeof(float));
+        const BufRsrc rd = dasr_make_rsrc(a.dy + (size_t)b * a.H * a.W * a.Cout, (size_t)a.H * a.W * a.Cout * sizeof(float));
         auto ldx = [&](int u) {
             const int idx = tid + 256 * u;
             const int c4 = idx % (CIG / 4), pix = idx / (CIG / 4);
             const int gy = y0 + pix / HW - 1, gx = x0 + pix % HW - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = *(const float4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + ci0 + 4 * c4);
+            const bool ok = idx < NX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const u32x4_t r = dasr_buffer_load16(rx, ok ? (unsigned)(((gy * a.W + gx) * a.Cin + ci0 + 4 * c4) * (int)sizeof(float)) : DASR_OOB);
+            float4 v;
+            __builtin_memcpy(&v, &r, 16);
             return v;
         };
         auto stx = [&](int u, float4 v) {
@@ -1226,10 +1231,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split2(SplitWgradArgs 
             const int idx = tid + 256 * u;
             const int c4 = idx % (COG / 4), pix = idx / (COG / 4);
             const int gy = y0 + pix / SW_TW, gx = x0 + pix % SW_TW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < ND && gy < a.H && gx < a.W)
-                v = *(const float4*)(a.dy + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * c4);
-            vd[u] = v;
+            const bool ok = idx < ND && gy < a.H && gx < a.W;
+            const u32x4_t r = dasr_buffer_load16(rd, ok ? (unsigned)(((gy * a.W + gx) * a.Cout + co0 + 4 * c4) * (int)sizeof(float)) : DASR_OOB);
+            __builtin_memcpy(&vd[u], &r, 16);
         }
         __syncthreads();                        // every wave is done with the previous tile
 #pragma unroll
@@ -1370,7 +1374,8 @@ static int sw_launch(const float* x, const float* xmax, const float* dconv, cons
     // leave room for one workgroup per CU only (64 -> 32: 258 -> 327 us, 32 -> 32: 517 -> 556).  impl + 64 (A/B, tests): the
     // first version everywhere; impl + 128: the staged-split kernel everywhere.
     const int impl = dasr_get_conv_bf16_impl();
-    if (NP == 2 && (impl & 64) == 0 && (MT * NTW == 4 || (impl & 128) != 0)) {
+    const bool fits32 = (size_t)H * W * (Cin > Cout ? Cin : Cout) * sizeof(float) < ((size_t)1 << 31);    // (its 32-bit buffer offsets)
+    if (NP == 2 && (impl & 64) == 0 && (MT * NTW == 4 || (impl & 128) != 0) && fits32) {
         size_t lds2 = sizeof(f16_t) * 2 * (size_t)((th + 2) * (SW_TW + 2) * sw2_stride(32 * MT) + th * SW_TW * sw2_stride(32 * NTW));
         if (lds2 < 4 * 4096) lds2 = 4 * 4096;                     // (the bias-gradient exchange: 256 float4)
         if (MT == 2 && NTW == 2)      DASR_LAUNCH((k_conv3x3_wgrad_split2<2, 2>), grid, dim3(256), lds2, stream, a);

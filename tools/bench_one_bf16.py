@@ -2,7 +2,7 @@
 """One trunk convolution shape in a loop (for rocprofv3 --pmc runs).
 Usage: bench_one_bf16.py [fwd|dgrad|wgrad|split|splitw] [Cin Cout H W B [impl]]
   fwd / dgrad / wgrad: the bf16 kernels (impl: ops.set_conv_bf16_impl code - 1 first kernel, 16 / 32 persistent 4- / 8-wave)
-  split / splitw: the fp32 split-bf16 forward / weight gradient"""
+  split / splitw: the fp32 split forward / weight gradient in the bf16 x 3 scheme; split2 / split2w: in the fp16 x 2 scheme"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,6 +24,21 @@ if mode in ("split", "splitw"):
             ops.conv3x3_fwd_split(x, ws, bias, co)
         else:
             ops.conv3x3_wgrad_split(x, y)
+    torch.cuda.synchronize()
+    sys.exit(0)
+if mode in ("split2", "split2w"):
+    x = torch.randn(B, H, W, ci, device=dev)
+    wp = ops.pack_hwio(torch.randn(3, 3, ci, co, device=dev) * 0.05)
+    bias = torch.randn(co, device=dev)
+    ws = ops.conv3x3_split2_weights(wp)
+    xm = ops.absmax(x)
+    y = ops.conv3x3_fwd_split2(x, xm, ws, bias, co)
+    ym = ops.absmax(y)
+    for _ in range(5):
+        if mode == "split2":
+            ops.conv3x3_fwd_split2(x, xm, ws, bias, co)
+        else:
+            ops.conv3x3_wgrad_split2(x, xm, y, ym)
     torch.cuda.synchronize()
     sys.exit(0)
 x = torch.randn(B, H, W, ci, device=dev).to(BF)

@@ -1,4 +1,4 @@
-# SQ counters of the bf16 convolution kernels (first kernel / persistent 8-wave) and of the split-bf16 kernels: two passes each
+# SQ counters of the bf16 convolution kernels (first kernel / persistent 8-wave) and of the split kernels (bf16 x 3, fp16 x 2): two passes each
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r3pmc}; mkdir -p $O
 P1="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU"
@@ -12,8 +12,10 @@ run first fwd 128 128 256 320 32 1
 run v2 fwd 128 128 256 320 32 32
 run split split 128 128 128 160 16
 run splitw splitw 128 128 128 160 16
-python tools/pmc_conv.py $O/conv_sq_a.json first=$O/first_a v2=$O/v2_a split=$O/split_a splitw=$O/splitw_a > /dev/null
-python tools/pmc_conv.py $O/conv_sq_b.json first=$O/first_b v2=$O/v2_b split=$O/split_b splitw=$O/splitw_b > /dev/null
+run split2 split2 128 128 128 160 16
+run split2w split2w 128 128 128 160 16
+python tools/pmc_conv.py $O/conv_sq_a.json first=$O/first_a v2=$O/v2_a split=$O/split_a splitw=$O/splitw_a split2=$O/split2_a split2w=$O/split2w_a > /dev/null
+python tools/pmc_conv.py $O/conv_sq_b.json first=$O/first_b v2=$O/v2_b split=$O/split_b splitw=$O/splitw_b split2=$O/split2_b split2w=$O/split2w_b > /dev/null
 python - <<PY
 import json
 a, b = json.load(open("$O/conv_sq_a.json")), json.load(open("$O/conv_sq_b.json"))
