@@ -198,12 +198,14 @@ __device__ __forceinline__ SpScale sp_scales_take(const float* s_red) {
 // fragment, but all pieces had to be read before any was written: two more barriers per chunk.  Same speed on every shape,
 // A/B on one MI355X; this form has nothing to synchronise.)
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int NWV = SP_NWV>
 __device__ __forceinline__ void sp_presplit(char* hb, float sx, int tid) {
-    float4 raw[SP_NHP];
+    constexpr int NHP = SP_HBYTES / (1024 * NWV);              // pieces per thread: 5 (512 threads) / 10 (256)
+    float4 raw[NHP];
 #pragma unroll
-    for (int u = 0; u < SP_NHP; ++u) raw[u] = *(const float4*)(hb + 1024 * SP_NWV * u + 16 * tid);
+    for (int u = 0; u < NHP; ++u) raw[u] = *(const float4*)(hb + 1024 * NWV * u + 16 * tid);
 #pragma unroll
-    for (int u = 0; u < SP_NHP; ++u) {
+    for (int u = 0; u < NHP; ++u) {
         const float f[4] = {raw[u].x * sx, raw[u].y * sx, raw[u].z * sx, raw[u].w * sx};
         f16x8 o;
 #pragma unroll
@@ -212,7 +214,7 @@ __device__ __forceinline__ void sp_presplit(char* hb, float sx, int tid) {
             o[j] = h0;
             o[4 + j] = (f16_t)(f[j] - (float)h0);
         }
-        *(f16x8*)(hb + 1024 * SP_NWV * u + 16 * tid) = o;
+        *(f16x8*)(hb + 1024 * NWV * u + 16 * tid) = o;
     }
 }
 // fragment of plane pl for the lane's K-half lh at pixel P (byte address hb + 64 P)
@@ -228,8 +230,8 @@ __device__ __forceinline__ f16x8 sp_frag(const char* px, int lh, int key, int pl
 // ---- epilogue of one item: 32 channels per pass through [pixel][32 + 4] fp32 of the wave's scratch, 32 bytes per lane out;
 // residual, activation, accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue.  NP = 2: the sums are in
 // scaled units - times inv (the exact inverse of the two scales), plus the bias.
-template <int NT, int NP>
-__device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][NT], const ConvSplitArgs& a, char* const scr, const float* sBias,
+template <int NT, int NP, int RW = 2>
+__device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[RW][NT], const ConvSplitArgs& a, char* const scr, const float* sBias,
                                             const float inv, const int x0, const int y0, const int n0, const int bb,
                                             const int wv, const int lane, const int li, const int lh, float& om) {
     const int wvalid = a.W - x0;
@@ -237,8 +239,8 @@ __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][NT], const ConvSpli
     const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
     const bool has_act = a.act != DASR_ACT_NONE;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int gy = y0 + 2 * wv + m;
+    for (int m = 0; m < RW; ++m) {
+        const int gy = y0 + RW * wv + m;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -308,14 +310,18 @@ __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][NT], const ConvSpli
     }
 }
 
-template <int NT, int NP>
-__global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
+// RW = tile rows per wave.  2: eight waves (two per SIMD).  4 (fp16 x 2, 128 produced channels): FOUR waves, one per SIMD, each
+// with 4 x 4 accumulator tiles (256 registers: the unified 512-register file of a single-wave SIMD) - a kernel fragment read
+// from LDS then serves four tile rows instead of two (64 KB instead of 96 KB of operand reads per tap and CU).
+template <int NT, int NP, int RW = 2>
+__global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_split(ConvSplitArgs a) {
     DASR_DYN_SMEM(smem);
     typedef SpFrag<NP> F;
+    constexpr int NWV = SP_TH / RW, NTHR = 64 * NWV, NHP = SP_HBYTES / (16 * NTHR);
     constexpr int NTILE = 32 * NT, PIECE = NTILE * 32, SLAB = NP * PIECE;    // bytes: one 16-bit piece [NTILE][16], a K-step's NP
     constexpr int WP = SLAB / 16;                                            // DMA pieces per slice: 768 / 384 (NP = 2: 512 / 256)
-    constexpr int W1 = WP >= 512 ? 8 : WP / 64;                              // waves 0 .. W1-1 carry pieces 0 .. 511
-    constexpr int W2 = WP > 512 ? (WP - 512) / 64 : 0;                       // waves 0 .. W2-1 a second one (pieces 512 ..)
+    // a thread's pieces of a slice: WQ whole rounds of NTHR pieces (every wave), then waves 0 .. WR-1 one more
+    constexpr int WQ = WP / NTHR, WR = (WP - WQ * NTHR) / 64;
     char* const sH = smem;                              // [2][SP_HBYTES]
     // K-step = TPS taps of one 16-channel chunk between two barriers.  NP = 3: one tap (48 MFMAs per wave at NT = 4).  NP = 2:
     // a whole kernel ROW (three taps, 72 MFMAs): with half the products a one-tap step was as long as its own wait + barrier +
@@ -331,7 +337,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     const int li = lane & 31, lh = lane >> 5;
     // DMA pieces of a kernel slice per thread, NP = 3: NT = 4: 768 = 512 + 256 (waves 0-3 two, waves 4-7 one); NT = 2: 384
     // (waves 0-5 one, waves 6-7 none).  NP = 2: NT = 4: 512 (every wave one); NT = 2: 256 (waves 0-3).  A wave's count is static.
-    const int nwq = (wv < W1 ? 1 : 0) + (wv < W2 ? 1 : 0);
+    const int nwq = WQ + (wv < WR ? 1 : 0);
     const dasr_lds_addr_t ldsH = DASR_LDS_ADDR(sH) + 1024 * wv, ldsW = DASR_LDS_ADDR(sW) + 1024 * wv;
 
     const int xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3;
@@ -347,7 +353,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     const size_t sampb = (size_t)a.H * rowb;
     const char* const zp = (const char*)sp_zero_page;
 
-    for (int i = tid; i < a.Cout; i += SP_NTHR) sBias[i] = a.bias ? a.bias[i] : 0.f;
+    for (int i = tid; i < a.Cout; i += NTHR) sBias[i] = a.bias ? a.bias[i] : 0.f;
     sp_scales_gather<NP>(a.xmax, a.wmax, sRed);
     __syncthreads();
     const SpScale sc = sp_scales_take<NP>(sRed);
@@ -362,7 +368,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
         on0 = ns * NTILE;
     };
     decode(item, x0, y0, n0, bb);
-    int hoff[SP_NHP];
+    int hoff[NHP];
     unsigned hok = 0;
     const char* hxb;
     auto halo_setup = [&](int fx0, int fy0, int fb, bool real) {
@@ -374,8 +380,8 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
 #endif
         hok = 0;
 #pragma unroll
-        for (int u = 0; u < SP_NHP; ++u) {
-            const int P = (t >> 2) + (SP_NTHR / 4) * u;
+        for (int u = 0; u < NHP; ++u) {
+            const int P = (t >> 2) + (NTHR / 4) * u;
             const int pr = P / SP_HW, pc = P - pr * SP_HW;
             hoff[u] = org + pr * rowb + pc * pixb + 16 * ((t & 3) ^ ((P >> 2) & 3));
             const bool ok = real && P < SP_HPIX && (unsigned)(fy0 - 1 + pr) < (unsigned)a.H && (unsigned)(fx0 - 1 + pc) < (unsigned)a.W;
@@ -384,7 +390,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
     };
     auto halo_issue = [&](int u, int cc, int buf) {
         const char* src = ((hok >> u) & 1u) ? hxb + hoff[u] + 64 * cc : zp;
-        DASR_GLDS16(src, ldsH + buf * SP_HBYTES + 1024 * SP_NWV * u);
+        DASR_GLDS16(src, ldsH + buf * SP_HBYTES + 1024 * NWV * u);
     };
     // slices of K-step st (taps TPS st .. TPS st + TPS - 1) of chunk cc, slice fn0: SLAB bytes each at
     // ((ns * 9 + tap) * NC + cc) * SLAB, into ring slot st % R
@@ -394,24 +400,26 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
             const int tap = TPS * st + j;
             const char* src = (const char*)a.ws + (size_t)(((fn0 / NTILE) * 9 + tap) * NC + cc) * SLAB + 16 * tid;
             const dasr_lds_addr_t dst = ldsW + ((st % R) * TPS + j) * SLAB;
-            if (wv < W1) DASR_GLDS16(src, dst);                                             // pieces 0 .. 511 (or fewer)
-            if (wv < W2) DASR_GLDS16(src + 16 * SP_NTHR, dst + 1024 * SP_NWV);              // pieces 512 .. 767
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) DASR_GLDS16(src + 16 * NTHR * q, dst + 1024 * NWV * q);
+            if (WR > 0 && wv < WR) DASR_GLDS16(src + 16 * NTHR * WQ, dst + 1024 * NWV * WQ);
         }
     };
     // halo pieces of the NEXT chunk issued in step st: all of them at least D - 1 = one whole step before that chunk's first
     // step (whose wait lets the operations of the step before it stay in flight): one per step in steps 0 .. 4 of nine, three
     // and two in steps 0 and 1 of three
-    auto halo_first = [](int st) { return TPS == 1 ? st : (st == 0 ? 0 : (st == 1 ? 3 : SP_NHP)); };
-    auto halo_count = [](int st) { return TPS == 1 ? (st < SP_NHP ? 1 : 0) : (st == 0 ? 3 : (st == 1 ? SP_NHP - 3 : 0)); };
+    constexpr int HC0 = (NHP + 1) / 2;
+    auto halo_first = [](int st) { return TPS == 1 ? st : (st == 0 ? 0 : (st == 1 ? HC0 : NHP)); };
+    auto halo_count = [](int st) { return TPS == 1 ? (st < NHP ? 1 : 0) : (st == 0 ? HC0 : (st == 1 ? NHP - HC0 : 0)); };
 
-    const int Pl = 2 * wv * SP_HW + li;
+    const int Pl = RW * wv * SP_HW + li;
     const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4);
 
     int par = 0;
     float om = 0.f;                                     // running max |y| of this lane (a.ymax)
     halo_setup(x0, y0, bb, true);
 #pragma unroll
-    for (int u = 0; u < SP_NHP; ++u) halo_issue(u, 0, 0);
+    for (int u = 0; u < NHP; ++u) halo_issue(u, 0, 0);
 #pragma unroll
     for (int t = 0; t < D; ++t) w_issue(0, t, n0);
 
@@ -421,7 +429,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
         int nx0 = x0, ny0 = y0, nn0 = n0, nb = bb;
         if (has_next) decode(nitem, nx0, ny0, nn0, nb);
 
-        f32x16 acc[2][NT];
+        f32x16 acc[RW][NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -429,7 +437,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
                 float4 bv = *(const float4*)(sBias + n0 + 32 * n + 8 * g + 4 * lh);
                 if (NP == 2) bv = make_float4(0.f, 0.f, 0.f, 0.f);         // (scaled sums: the bias joins in the epilogue)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < RW; ++m) {
                     acc[m][n][4 * g] = bv.x; acc[m][n][4 * g + 1] = bv.y;
                     acc[m][n][4 * g + 2] = bv.z; acc[m][n][4 * g + 3] = bv.w;
                 }
@@ -451,7 +459,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
                     sp_wait_vm_n(nh + (D - 1) * TPS * nwq);
                 }
                 if (NP == 2 && st == 0) {              // this chunk's halo pieces - this thread's own - have landed: split them
-                    sp_presplit(sH + par * SP_HBYTES, sc.sx, tid);
+                    sp_presplit<NWV>(sH + par * SP_HBYTES, sc.sx, tid);
                     DASR_LDS_BARRIER();
                 } else {
                     DASR_RAW_BARRIER();
@@ -469,9 +477,9 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
 #ifndef DASR_HIPEMU
                 asm volatile("" : "+v"(Pq));
 #endif
-                typename F::type A[2][NP];
+                typename F::type A[RW][NP];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < RW; ++m) {
                     const int P = Pq + (m + dy) * SP_HW + dx;
                     const int key = (P >> 2) & 3;
                     if constexpr (NP == 2) {            // pre-split pieces (sp_presplit)
@@ -491,7 +499,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
 #pragma unroll
                     for (int j = 0; j < NP; ++j) Bw[j] = *(const typename F::type*)(wb + j * PIECE + n * 1024);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m][n] = F::mma(Bw, A[m], acc[m][n]);     // smallest terms first
+                    for (int m = 0; m < RW; ++m) acc[m][n] = F::mma(Bw, A[m], acc[m][n]);     // smallest terms first
                 }
                 DASR_SETPRIO(0);
                 }
@@ -503,7 +511,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split(ConvSplitArgs a) {
         // accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue
         DASR_RAW_BARRIER();
         char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
-        sp_epilogue<NT, NP>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh, om);
+        sp_epilogue<NT, NP, RW>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh, om);
         if (!has_next) break;
         item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
     }
@@ -846,7 +854,10 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
                        sizeof(float) * (size_t)(a.Cout + 32);
     if (lds > 160 * 1024) return DASR_E_UNSUPPORTED;
     const dim3 grid(8 * a.G8);
-    if (NT == 4)      DASR_LAUNCH((k_conv3x3_split<4, NP>), grid, dim3(SP_NTHR), lds, stream, a);
+    // (impl + 256, A/B: the four-wave form - four tile rows per wave - of the fp16 x 2 kernel at 128 produced channels)
+    if (NT == 4 && NP == 2 && (dasr_get_conv_bf16_impl() & 256) != 0)
+        DASR_LAUNCH((k_conv3x3_split<4, 2, 4>), grid, dim3(256), lds, stream, a);
+    else if (NT == 4) DASR_LAUNCH((k_conv3x3_split<4, NP>), grid, dim3(SP_NTHR), lds, stream, a);
     else if (NT == 2) DASR_LAUNCH((k_conv3x3_split<2, NP>), grid, dim3(SP_NTHR), lds, stream, a);
     else              DASR_LAUNCH((k_conv3x3_split_n32<NP>), grid, dim3(SP_NTHR), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
