@@ -32,9 +32,9 @@ import threading as _threading
 TAIL_WGRAD_SIDE = False  # weight gradients of the HR tail on the (then idle) depth-branch stream; see conv(side_wgrad=)
 FUSE_INSTNORM_STATS = False  # measured: 115.5 -> 111.5 frames/s when on (two more barriers + reductions in the 64->64 conv epilogue cost more than the statistics pass they replace); the entry point stays, tested
 ENCODER_S2D = True     # bf16 path: encoder layers 2-5 on the bf16 stride-1 kernels (space-to-depth form); False: fp32 gather kernels
-# fp32 path: the plain (bias-only) 3x3 trunk convolutions - gamma_o|beta_o 128 -> 128 and the DGB 64 -> 64 ones, forward and
-# dgrad - at fp32 accuracy on the BF16 matrix cores (csrc/conv_split_bf16.hip: three bf16 pieces per operand, six products).
-# Weight gradients stay on the exact-fp32 MFMA kernels.
+# fp32 path: every 3x3 / stride 1 trunk convolution with channel counts that are multiples of 32 (gamma_o|beta_o 128 -> 128, the
+# DGB 64 -> 64 ones, the HR tail) - forward, dgrad and weight gradient - at fp32 accuracy on the 16-bit matrix cores
+# (csrc/conv_split_bf16.hip); False: the exact-fp32 MFMA kernels everywhere.
 SPLIT_BF16 = True
 SPLIT_WGRAD = True              # ... and their weight gradients (K = pixels: operands split at read time)
 # 3: three bf16 pieces, six products.  2: two fp16 pieces, three products, every tensor operand scaled by a power of two taken

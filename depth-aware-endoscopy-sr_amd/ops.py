@@ -427,7 +427,7 @@ def conv2d_wgrad_act(x, dy, y, w_shape, act, stride=1, pad=1, transposed=False, 
     return dw, db
 
 
-# ---- fp32 convolutions on the bf16 matrix cores (split bf16) --------------------------------
+# ---- fp32 convolutions on the bf16 matrix cores (split bf16 x 3: three pieces per operand, six products) -------
 def conv3x3_split_supported(H, W, Cin, Cout):
     return bool(_lib.get().dasr_conv3x3_split_supported(H, W, Cin, Cout))
 
