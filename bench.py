@@ -240,6 +240,22 @@ class SplitTimer:
                             "dense bf16 / fp16 MFMA rate" % n}
 
 
+def arithmetic_note(dtype):
+    """How the configuration computes, in words (config.arithmetic): `dtype` names storage and accumulation; the fp32 path's
+    convolutions run as split products on the 16-bit matrix cores at fp32 accuracy unless --no-split."""
+    from dasr_amd import graph as g
+    if dtype != "f32":
+        return "bf16 activations and bf16 MFMA operands, fp32 accumulators / statistics / master weights"
+    if not g.SPLIT_BF16:
+        return "fp32 tensors, exact-fp32 MFMA convolutions (v_mfma_f32_32x32x2_f32)"
+    if g.SPLIT_PIECES == 2:
+        return ("fp32 tensors and fp32 accumulation; 3x3 trunk convolutions%s as fp16 x 2 split products (two scaled fp16 pieces per "
+                "operand, three MFMA products per term): error against float64 below the exact-fp32 MFMA kernels', same parity "
+                "gates (DESIGN.md 4.11); --no-split runs the exact-fp32 kernels" % (" and the 9x9 output convolution" if g.SPLIT_CONV9 else ""))
+    return ("fp32 tensors and fp32 accumulation; 3x3 trunk convolutions as bf16 x 3 split products (three bf16 pieces per operand, six "
+            "MFMA products per term): fp32-grade (DESIGN.md 4.11); --no-split runs the exact-fp32 kernels")
+
+
 def mfma_roofline(net, args, B, elapsed, timer_conv, config):
     """bf16 configs (c3, c4): the step is bound by the bf16 matrix cores.  `achieved` = algorithmic FLOPs of one launch of the
     dominant kernel (k_conv3x3_bf16 on the 128 -> 128 gamma_o|beta_o convolution, 2*9*128*128 FLOP per pixel) / its
@@ -606,7 +622,7 @@ def main():
             "config": {"workload": cfg["workload"] % B,
                        "global_batch": world * B, "lr_hw": [LR_H, LR_W], "scale": SCALE,
                        "parallelism": "dp%d" % world, "mode": args.mode, "device": args.device,
-                       "hip_graph": bool(use_graph)},
+                       "hip_graph": bool(use_graph), "arithmetic": arithmetic_note(cfg["dtype"])},
             "loss": round(loss, 6) if loss == loss else None,
             "roofline": roof,
             "roofline_b32": roof32,
