@@ -1,6 +1,11 @@
-// conv_split_bf16.hip — fp32 3x3 / stride 1 / pad 1 convolutions (forward and dgrad) at fp32 accuracy on the BF16 matrix
-// cores: "split bf16".  For the fp32 path's plain trunk convolutions (bias only): mlp_gamma_o | mlp_beta_o
-// (normalization.py:41-42,73-74: 128 -> 128, 41 % of the x8 step) and the DGB convolutions (sftmd_arch.py:811-820: 64 -> 64).
+// conv_split_bf16.hip — fp32 3x3 / stride 1 / pad 1 convolutions (forward, dgrad, weight gradient) at fp32 accuracy on the
+// 16-bit matrix cores: operands split into 16-bit pieces.  For the fp32 path's trunk convolutions: mlp_gamma_o | mlp_beta_o
+// (normalization.py:41-42,73-74: 128 -> 128, 41 % of the x8 step), the DGB convolutions (sftmd_arch.py:811-820: 64 -> 64), the
+// classic blocks and the upscale tail (:128-146, :891-908).  Two schemes, selected by the template parameter NP (pieces per
+// operand): NP = 3, three bf16 pieces / six products (first); NP = 2, two scaled fp16 pieces / three products (the default of
+// graph.py, below).  File layout: scale / split helpers; forward + dgrad kernels (k_conv3x3_split, _n32) with the in-place
+// halo split (sp_presplit) and the shared epilogue; k_split_weights, k_absmax; the C ABI; the weight-gradient kernels
+// (k_conv3x3_wgrad_split: fp32 tiles split per K-step; k_conv3x3_wgrad_split2: fp16 planes split at staging time).
 //
 // Why.  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate and the fp32 kernels of conv_mfma.hip already sit at 81-85 % of
 // that peak: the fp32 step has no other lever left.  An fp32 value is the exact sum of three bf16 pieces
@@ -33,7 +38,10 @@
 // [2^14, 2^15) - dasr_absmax leaves the maximum in device memory, the kernels derive the scale from its exponent, nothing
 // goes through the host - so that x1 stays a normal number down to 2^-18 of the tensor's maximum and loses absolute, never
 // relative-to-the-sum, precision below (floor: 2^-40 of the maximum).  The result is multiplied by the exact inverse of
-// the two scales in the epilogue (bias added there).
+// the two scales in the epilogue (bias added there).  Differences of the NP = 2 kernels from the structure above: the
+// landed halo chunk is split once, in place, by the threads that fetched it (sp_presplit) instead of at every read; a K-step
+// is a whole kernel row (three taps, 72 MFMAs between barriers); the maxima arrive as amax buffers (dasr_common.h) filled by
+// the kernels that produced the tensors, and the epilogue leaves the maximum of what it stores for the next convolution.
 #include "bf16.h"
 #include "conv_kernels.h"
 
