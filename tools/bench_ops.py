@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--amax", action="store_true", help="SEAN forward: the instantiation that also leaves max |out| behind")
     a = ap.parse_args()
     dev = torch.device("cuda")
     B, H, W, C, K = a.batch, 128, 160, 64, 10
@@ -50,7 +51,8 @@ def main():
         us = timeit(lambda: ops.instnorm_stats(t), a.iters)
         print("instnorm_stats            %8.1f us  %7.1f GB/s" % (us, px * C * 4 / us / 1e3))
         for name, r in (("sean_fwd", None), ("sean_fwd+res", resid)):
-            us = timeit(lambda: ops.sean_fwd(t, mean, var, gb2, mk, region, flag, D, bg, bb, ag, ab, r, True), a.iters)
+            am = ops.amax_buffer(t) if a.amax else None      # (--amax: the instantiation that also keeps max |out|)
+            us = timeit(lambda: ops.sean_fwd(t, mean, var, gb2, mk, region, flag, D, bg, bb, ag, ab, r, True, amax=am), a.iters)
             nbytes = px * (4 * (4 * C + (C if r is not None else 0)) + 4 * K)
             print("%-25s %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (name, us, nbytes / us / 1e3,
                                                                                  nbytes / us / 1e3 / 80))
