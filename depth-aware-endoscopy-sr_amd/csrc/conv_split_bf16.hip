@@ -1394,13 +1394,12 @@ static int sw_launch(const float* x, const float* xmax, const float* dconv, cons
     SplitWgradArgs a{xmax, dmax, x, dconv, slabs, bslabs, ysplit > 1 ? dw : nullptr, ysplit > 1 ? nW : 0, B, H, W, Cin, Cout, P, ntiles};
     const int th = sw_th(MT, NTW);
     const dim3 grid(groups, P);
-    // fp16 x 2: blocks of four (ci, co) pairs take the staged-split kernel (128 -> 128 424 -> 347 us, 64 -> 64 134 -> 115, 32 -> 128
-    // at 512 x 640 1716 -> 1433); the smaller blocks keep the first version - their taller tiles in two padded fp16 planes
-    // leave room for one workgroup per CU only (64 -> 32: 258 -> 327 us, 32 -> 32: 517 -> 556).  impl + 64 (A/B, tests): the
-    // first version everywhere; impl + 128: the staged-split kernel everywhere.
+    // fp16 x 2: the staged-split kernel (128 -> 128 424 -> 317 us, 64 -> 64 134 -> 107, 32 -> 128 at 512 x 640 1716 -> 1349, 32 -> 32
+    // there 544 -> 435, 64 -> 32 277 -> 265; before its staging went through buffer descriptors the small blocks lost with it).
+    // impl + 64 (A/B, tests): the first version - fp32 tiles, operands split per K-step.
     const int impl = dasr_get_conv_bf16_impl();
     const bool fits32 = (size_t)H * W * (Cin > Cout ? Cin : Cout) * sizeof(float) < ((size_t)1 << 31);    // (its 32-bit buffer offsets)
-    if (NP == 2 && (impl & 64) == 0 && (MT * NTW == 4 || (impl & 128) != 0) && fits32) {
+    if (NP == 2 && (impl & 64) == 0 && fits32) {
         size_t lds2 = sizeof(f16_t) * 2 * (size_t)((th + 2) * (SW_TW + 2) * sw2_stride(32 * MT) + th * SW_TW * sw2_stride(32 * NTW));
         if (lds2 < 4 * 4096) lds2 = 4 * 4096;                     // (the bias-gradient exchange: 256 float4)
         if (MT == 2 && NTW == 2)      DASR_LAUNCH((k_conv3x3_wgrad_split2<2, 2>), grid, dim3(256), lds2, stream, a);

@@ -352,7 +352,7 @@ int dasr_conv2d_epilogue_bwd_bf16(const unsigned short* dy, const unsigned short
  * it applies (Cin % 32 == 0, Cout % 64 == 0, PixelShuffle 1 or 2), 1 = the first, register-staged kernel everywhere,
  * 2 = the persistent kernel with one workgroup per XCD (tests: long per-workgroup item lists on small shapes);
  * + 16 = force its 8-row / 4-wave form, + 32 = its 16-row / 8-wave form (default: by problem size);
- * + 64 / + 128 = the fp16 x 2 split weight gradient: its first kernel / its staged-split kernel for every block shape;
+ * + 64 = the fp16 x 2 split weight gradient on its first kernel (operands split per K-step; default: split at staging);
  * + 256 = the fp16 x 2 split forward / dgrad at 128 produced channels in its four-wave form (four tile rows per wave).
  * For A/B measurements and tests; process-wide, not thread-safe against concurrent launches.
  * dasr_conv_bf16_v2_launches(): how many times the persistent kernel has been launched by this process. */

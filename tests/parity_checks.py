@@ -1362,10 +1362,9 @@ def check_split_conv(device, seed=5, pieces=3):
     fac, slack = (3.0, 2e-7) if device == "cpu" else (1.25, 1e-7)
     api = _SplitApi(pieces)
     sx_, sd_ = (665.6, 3e-8) if pieces == 2 else (1.0, 1.0)
-    # (impl + 64 / + 128: the first / the staged-split fp16 x 2 weight-gradient kernel for EVERY block shape - by default the
-    # block shape picks one; GPU only)
+    # (impl + 64: the first fp16 x 2 weight-gradient kernel - operands split per K-step - for every block shape; GPU only)
     # impl + 256: the four-wave form of the forward / dgrad kernel at 128 produced channels (four tile rows per wave)
-    for mode in (0, 2) + ((64, 128, 256, 258) if pieces == 2 and device != "cpu" else ((256,) if pieces == 2 else ())):
+    for mode in (0, 2) + ((64, 256, 258) if pieces == 2 and device != "cpu" else ((256,) if pieces == 2 else ())):
         one_wg = mode
         ops.set_conv_bf16_impl(mode)
         shapes = [(64, 64, 1, 17, 35), (128, 128, 1, 16, 32), (128, 64, 2, 33, 40), (64, 256, 1, 9, 70)]
@@ -1417,7 +1416,7 @@ def check_split_conv(device, seed=5, pieces=3):
                        (64, 256, 2, False, 2, 1, 16, 32)]
             if device == "cpu":
                 eshapes = eshapes[:2] if mode == 0 else eshapes[2:3]
-            if mode in (64, 128):
+            if mode == 64:
                 eshapes = eshapes[:3]
             if mode in (256, 258):
                 eshapes = eshapes[2:] if device != "cpu" else eshapes[2:3]
