@@ -495,8 +495,6 @@ struct WgradBf16Args {
     const bf16_t* dy;    // [B,H,W,Cout]
     float* slabs;        // [P][9][Cin][Cout]
     float* bslabs;       // [P][Cout] or null
-    float* zero;         // dw when the reduction will add into it with atomics, else null: zeroed here
-    size_t nzero;
     int B, H, W, Cin, Cout;
     int P, ntiles;
 };
@@ -528,10 +526,6 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_bf16(WgradBf16Args a) 
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const bool do_bias = a.bslabs != nullptr && ci0 == 0 && tid < COG;
     float bsum = 0.f;
-    if (a.zero) {
-        const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
-        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
-    }
     // transposed-read lane roles: lane 4q+p of its 16-lane group passes the address of pixel row q, channels 4p..4p+3 of the
     // group's 16 channels; groups 0,1 cover channels 0..15 / 16..31 of pixels 0..7 of the K-step, groups 2,3 pixels 8..15
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
@@ -685,12 +679,6 @@ size_t conv_bf16_wgrad_workspace(const ConvGeom& g) {
     wb_plan(g, MT, NTW, groups, ntiles, P);
     return sizeof(float) * ((size_t)P * 9 * g.Cin * g.Cout + (size_t)P * g.Cout);
 }
-static int wb_ysplit(size_t n4, int P) {       // the rule of conv_mfma.hip's wgrad_reduce_launch
-    unsigned gx = dasr_cdiv(n4, 256);
-    int ysplit = 1;
-    while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
-    return ysplit;
-}
 int conv_bf16_wgrad(const ConvGeom& g, const bf16_t* x, const bf16_t* dconv, float* dw, float* dbias, void* workspace,
                     void* stream) {
     int MT, NTW, groups, ntiles, P;
@@ -698,8 +686,7 @@ int conv_bf16_wgrad(const ConvGeom& g, const bf16_t* x, const bf16_t* dconv, flo
     const size_t nW = (size_t)9 * g.Cin * g.Cout;
     float* slabs = (float*)workspace;
     float* bslabs = dbias ? slabs + (size_t)P * nW : nullptr;
-    const bool ysplit = wb_ysplit(nW / 4, P) > 1;
-    WgradBf16Args a{x, dconv, slabs, bslabs, ysplit ? dw : nullptr, ysplit ? nW : 0, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
+    WgradBf16Args a{x, dconv, slabs, bslabs, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
     const int th = wb_th(MT, NTW);
     const size_t lds = sizeof(bf16_t) * (size_t)((th + 2) * (WB_TW + 2) * wb_stride(32 * MT) + th * WB_TW * wb_stride(32 * NTW));
     dim3 grid(groups, P);
@@ -707,5 +694,5 @@ int conv_bf16_wgrad(const ConvGeom& g, const bf16_t* x, const bf16_t* dconv, flo
     else if (MT == 2 && NTW == 1) DASR_LAUNCH((k_conv3x3_wgrad_bf16<2, 1>), grid, dim3(256), lds, stream, a);
     else if (MT == 1 && NTW == 2) DASR_LAUNCH((k_conv3x3_wgrad_bf16<1, 2>), grid, dim3(256), lds, stream, a);
     else                          DASR_LAUNCH((k_conv3x3_wgrad_bf16<1, 1>), grid, dim3(256), lds, stream, a);
-    return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit, bslabs, dbias, g.Cout);
+    return wgrad_reduce_launch(slabs, dw, nW, P, stream, bslabs, dbias, g.Cout);
 }

@@ -59,8 +59,8 @@ int conv_gather_fwd(const ConvGeom& g, const float* x, const float* w, const flo
 int conv_gather_dgrad(const ConvGeom& g, const float* dconv, const float* w, float* dx, int accumulate, void* stream);
 size_t conv_gather_wgrad_workspace(const ConvGeom& g);
 int conv_gather_wgrad(const ConvGeom& g, const float* x, const float* dconv, float* dw, void* workspace, void* stream);
-int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* stream, bool dw_is_zero = false,
-                        const float* bslabs = nullptr, float* dbias = nullptr, int Cout = 0);
+int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* stream, const float* bslabs = nullptr,
+                        float* dbias = nullptr, int Cout = 0);
 
 // conv_c1.hip (3x3, Cin == 1: SEAN.mlp_mask on the depth map)
 bool conv_c1_supported(const ConvGeom& g);

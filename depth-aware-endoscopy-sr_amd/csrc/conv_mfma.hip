@@ -526,8 +526,6 @@ struct WgradArgs {
     const float* dy;     // [B,H,W,Cout]
     float* slabs;        // [P][9][Cin][Cout]
     float* bslabs;       // [P][Cout] or null: column sums of dy (bias gradient partials) written by the ci-group-0 workgroups
-    float* zero;         // dw when the reduction will add into it with atomics (y-split), else null: zeroed here
-    size_t nzero;
     int B, H, W, Cin, Cout;
     int P, ntiles;
 };
@@ -556,10 +554,6 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_mfma(WgradArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const bool do_bias = a.bslabs != nullptr && ci0 == 0 && tid < COG;
     float bsum = 0.f;
-    if (a.zero) {                                // spares a memset launch: dw is only touched by the reduce kernel after us
-        const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
-        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
-    }
 
     for (int tile = blockIdx.y; tile < a.ntiles; tile += a.P) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
@@ -670,10 +664,12 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_mfma(WgradArgs a) {
     }
 }
 
-// dw = sum of P slabs.  float4 per thread, the slab range split over blockIdx.y (partial sums meet in dw through
-// float atomics when gridDim.y > 1; dw is zeroed first).
+// dw = sum of P slabs in a fixed order (bitwise reproducible, no atomics, nothing to clear).  A workgroup owns 256 / Q float4
+// columns; its Q thread groups sum the slabs q, q + Q, ... with eight loads in flight per thread (the slabs were just written:
+// they come from L2 / MALL, so the latency chain, not the bytes, is what a launch waits for) and meet in LDS.
+template <int Q>
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, size_t n4,
-                                                      int P, int per_y, int gx, const float* __restrict__ bslabs,
+                                                      int P, int gx, const float* __restrict__ bslabs,
                                                       float* __restrict__ dbias, int Cout) {
     if ((int)blockIdx.x >= gx) {                 // tail blocks: bias gradient = fixed-order sum of the P partials
         // 32 channels per block, 8 slab parts per channel, eight loads in flight per thread (a one-load-per-trip
@@ -681,7 +677,6 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
         __shared__ float bpart[8][32];
         const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
         const int c = (blockIdx.x - gx) * 32 + cl;
-        if (blockIdx.y != 0) return;
         float acc = 0.f;
         if (c < Cout) {
             for (int p0 = q; p0 < P; p0 += 64) {
@@ -702,52 +697,49 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
         }
         return;
     }
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const int p0 = blockIdx.y * per_y;
-    const int p1 = p0 + per_y < P ? p0 + per_y : P;
-    const float4* src = (const float4*)slabs + i;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    int p = p0;
-    for (; p + 1 < p1; p += 2) {
-        float4 v0 = src[(size_t)p * n4], v1 = src[(size_t)(p + 1) * n4];
-        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    constexpr int COLS = 256 / Q;
+    __shared__ float4 part[256];
+    const int col = threadIdx.x % COLS, q = threadIdx.x / COLS;
+    const size_t i = (size_t)blockIdx.x * COLS + col;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const float4* src = (const float4*)slabs + i;
+        for (int p0 = q; p0 < P; p0 += 8 * Q) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = p0 + u * Q < P ? src[(size_t)(p0 + u * Q) * n4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
     }
-    if (p < p1) {
-        float4 v0 = src[(size_t)p * n4];
-        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-    }
-    a0.x += a1.x; a0.y += a1.y; a0.z += a1.z; a0.w += a1.w;
-    float* d = dw + 4 * i;
-    if (gridDim.y == 1) {
-        *(float4*)d = a0;
-    } else {
-        atomicAdd(d + 0, a0.x); atomicAdd(d + 1, a0.y); atomicAdd(d + 2, a0.z); atomicAdd(d + 3, a0.w);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (q == 0 && i < n4) {
+        float4 r = part[col];
+#pragma unroll
+        for (int t = 1; t < Q; ++t) {
+            const float4 o = part[t * COLS + col];
+            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+        }
+        ((float4*)dw)[i] = r;
     }
 }
 
-static int wgrad_reduce_ysplit(size_t n4, int P) {
-    unsigned gx = dasr_cdiv(n4, 256);
-    int ysplit = 1;
-    while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
-    return ysplit;
-}
-// dw_is_zero: the producer already cleared dw (k_conv3x3_wgrad_mfma does when asked); bslabs/dbias: optional bias tail
-int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* stream, bool dw_is_zero,
-                        const float* bslabs, float* dbias, int Cout) {
+// bslabs / dbias: optional bias tail
+int wgrad_reduce_launch(const float* slabs, float* dw, size_t n, int P, void* stream, const float* bslabs, float* dbias,
+                        int Cout) {
     // n is a multiple of 4 for every supported shape (Cout % 32 == 0)
-    size_t n4 = n / 4;
-    unsigned gx = dasr_cdiv(n4, 256);
-    const int ysplit = wgrad_reduce_ysplit(n4, P);
-    int per_y = (P + ysplit - 1) / ysplit;
-    if (ysplit > 1 && !dw_is_zero) {
-        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * n, (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-    }
+    const size_t n4 = n / 4;
+    int Q = 4;                                   // thread groups per column: enough workgroups to cover the chip
+    while (Q < 32 && dasr_cdiv(n4, (size_t)(256 / Q)) < 512 && 2 * Q <= P) Q *= 2;
+    const unsigned gx = dasr_cdiv(n4, (size_t)(256 / Q));
     const unsigned tail = dbias ? dasr_cdiv((size_t)Cout, 32) : 0;
-    DASR_LAUNCH(k_wgrad_reduce, dim3(gx + tail, ysplit), dim3(256), 0, stream, slabs, dw, n4, P, per_y, (int)gx, bslabs,
-                dbias, Cout);
+    const dim3 grid(gx + tail);
+    if (Q == 4)       DASR_LAUNCH((k_wgrad_reduce<4>), grid, dim3(256), 0, stream, slabs, dw, n4, P, (int)gx, bslabs, dbias, Cout);
+    else if (Q == 8)  DASR_LAUNCH((k_wgrad_reduce<8>), grid, dim3(256), 0, stream, slabs, dw, n4, P, (int)gx, bslabs, dbias, Cout);
+    else if (Q == 16) DASR_LAUNCH((k_wgrad_reduce<16>), grid, dim3(256), 0, stream, slabs, dw, n4, P, (int)gx, bslabs, dbias, Cout);
+    else              DASR_LAUNCH((k_wgrad_reduce<32>), grid, dim3(256), 0, stream, slabs, dw, n4, P, (int)gx, bslabs, dbias, Cout);
     DASR_RETURN_LAUNCH_STATUS();
 }
 
@@ -780,8 +772,7 @@ int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float
     const size_t nW = (size_t)9 * g.Cin * g.Cout;
     float* slabs = (float*)workspace;
     float* bslabs = dbias ? slabs + (size_t)P * nW : nullptr;
-    const bool ysplit = wgrad_reduce_ysplit(nW / 4, P) > 1;
-    WgradArgs a{x, dconv, slabs, bslabs, ysplit ? dw : nullptr, ysplit ? nW : 0, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
+    WgradArgs a{x, dconv, slabs, bslabs, g.B, g.H, g.W, g.Cin, g.Cout, P, ntiles};
     const int th = wg_th(MT, NTW);
     size_t lds = sizeof(float) * (size_t)((th + 2) * (WG_TW + 2) * 32 * MT + th * WG_TW * 32 * NTW);
     dim3 grid(groups, P);
@@ -796,5 +787,5 @@ int conv_mfma_wgrad(const ConvGeom& g, const float* x, const float* dconv, float
     } else {
         DASR_LAUNCH((k_conv3x3_wgrad_mfma<1, 1>), grid, dim3(256), lds, stream, a);
     }
-    return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit, bslabs, dbias, g.Cout);
+    return wgrad_reduce_launch(slabs, dw, nW, P, stream, bslabs, dbias, g.Cout);
 }

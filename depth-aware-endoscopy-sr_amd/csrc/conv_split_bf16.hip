@@ -532,11 +532,12 @@ __global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_
 // against ~420 us of matrix time on the x8 bench's fourteen launches).  The kernel slices of a chunk are tiny here (9 taps x
 // 3 KB), so ALL NINE are fetched with the halo chunk, double-buffered by chunk: one wait + barrier per CHUNK (108 MFMAs per
 // wave), the nine taps run free of synchronisation and the compiler pipelines reads, splits and MFMAs across them.
-template <int NP>
+// (NT = 2, fp16 x 2 only, A/B behind impl + 512: the same one-barrier-per-chunk form for 64 produced channels - nine 4 KB slices.)
+template <int NP, int NT = 1>
 __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs a) {
     DASR_DYN_SMEM(smem);
     typedef SpFrag<NP> F;
-    constexpr int NT = 1, NTILE = 32, PIECE = NTILE * 32, SLAB = NP * PIECE;  // 3 KB (NP = 2: 2 KB) per (tap, chunk)
+    constexpr int NTILE = 32 * NT, PIECE = NTILE * 32, SLAB = NP * PIECE;     // NT = 1: 3 KB (NP = 2: 2 KB) per (tap, chunk)
     constexpr int WCH = 9 * SLAB, WPC = WCH / 16;                              // a chunk's nine slices: 27 KB = 1728 DMA pieces (18 KB = 1152)
     constexpr int WPT = SLAB / 16;                                             // pieces per tap: 192 (128)
     constexpr int WU = (WPC + SP_NTHR - 1) / SP_NTHR, WLAST = (WPC - (WU - 1) * SP_NTHR) / 64;   // trips; waves in the last one
@@ -631,15 +632,17 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
 
         f32x16 acc[2][NT];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 bv = *(const float4*)(sBias + n0 + 8 * g + 4 * lh);
-            if (NP == 2) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                acc[m][0][4 * g] = bv.x; acc[m][0][4 * g + 1] = bv.y;
-                acc[m][0][4 * g + 2] = bv.z; acc[m][0][4 * g + 3] = bv.w;
+            for (int g = 0; g < 4; ++g) {
+                float4 bv = *(const float4*)(sBias + n0 + 32 * n + 8 * g + 4 * lh);
+                if (NP == 2) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m][n][4 * g] = bv.x; acc[m][n][4 * g + 1] = bv.y;
+                    acc[m][n][4 * g + 2] = bv.z; acc[m][n][4 * g + 3] = bv.w;
+                }
             }
-        }
 
         for (int cc = 0; cc < NC; ++cc) {
             const bool last = cc == NC - 1;
@@ -679,11 +682,14 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
                     }
                 }
                 const char* const wb = wc + tap * SLAB;
-                typename F::type Bw[NP];
 #pragma unroll
-                for (int j = 0; j < NP; ++j) Bw[j] = *(const typename F::type*)(wb + j * PIECE);
+                for (int n = 0; n < NT; ++n) {
+                    typename F::type Bw[NP];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][0] = F::mma(Bw, A[m], acc[m][0]);
+                    for (int j = 0; j < NP; ++j) Bw[j] = *(const typename F::type*)(wb + j * PIECE + n * 1024);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][n] = F::mma(Bw, A[m], acc[m][n]);
+                }
             }
             par ^= 1;
         }
@@ -863,8 +869,9 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
     a.Q = (a.nitems + 7) / 8;
     a.G8 = a.Q < 32 ? a.Q : 32;
     if ((dasr_get_conv_bf16_impl() & 3) == 2) a.G8 = 1;        // tests: one workgroup per XCD walks every item of it
+    const bool chunk2 = NT == 2 && NP == 2 && (dasr_get_conv_bf16_impl() & 512) != 0;     // (A/B: 64 channels on the chunk form)
     const size_t lds = 2 * (size_t)SP_HBYTES +
-                       (NT == 1 ? 2 * (size_t)(9 * NP * 32 * 32) : 3 * (size_t)((NP == 2 ? 3 : 1) * NP * 32 * NT * 32)) +
+                       (NT == 1 || chunk2 ? 2 * (size_t)(9 * NP * 32 * NT * 32) : 3 * (size_t)((NP == 2 ? 3 : 1) * NP * 32 * NT * 32)) +
                        sizeof(float) * (size_t)(a.Cout + 32);
     if (lds > 160 * 1024) return DASR_E_UNSUPPORTED;
     const dim3 grid(8 * a.G8);
@@ -872,6 +879,7 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
     if (NT == 4 && NP == 2 && (dasr_get_conv_bf16_impl() & 256) != 0)
         DASR_LAUNCH((k_conv3x3_split<4, 2, 4>), grid, dim3(256), lds, stream, a);
     else if (NT == 4) DASR_LAUNCH((k_conv3x3_split<4, NP>), grid, dim3(SP_NTHR), lds, stream, a);
+    else if (chunk2)  DASR_LAUNCH((k_conv3x3_split_n32<2, 2>), grid, dim3(SP_NTHR), lds, stream, a);
     else if (NT == 2) DASR_LAUNCH((k_conv3x3_split<2, NP>), grid, dim3(SP_NTHR), lds, stream, a);
     else              DASR_LAUNCH((k_conv3x3_split_n32<NP>), grid, dim3(SP_NTHR), lds, stream, a);
     DASR_RETURN_LAUNCH_STATUS();
@@ -943,8 +951,6 @@ struct SplitWgradArgs {
     const float* dy;     // [B,H,W,Cout]
     float* slabs;        // [P][9][Cin][Cout]
     float* bslabs;       // [P][Cout] or null
-    float* zero;         // dw when the reduction adds into it with atomics, else null: zeroed here
-    size_t nzero;
     int B, H, W, Cin, Cout;
     int P, ntiles;
 };
@@ -1001,10 +1007,6 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split(SplitWgradArgs a
         for (int w = 1; w < nw; ++w) { mx = fmaxf(mx, s_red[w]); md = fmaxf(md, s_red[16 + w]); }
         const int kx = sp_scale_exp(mx), kd = sp_scale_exp(md);
         sx = sp_pow2(kx); sd = sp_pow2(kd); inv = sp_pow2(-(kx + kd));
-    }
-    if (a.zero) {
-        const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
-        for (size_t i = ((size_t)bpar * gridDim.x + bgrp) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
     }
 
     for (int tile = bpar; tile < a.ntiles; tile += a.P) {
@@ -1201,10 +1203,6 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_wgrad_split2(SplitWgradArgs 
         const int kx = sp_scale_exp(mx), kd = sp_scale_exp(md);
         sx = sp_pow2(kx); sd = sp_pow2(kd); inv = sp_pow2(-(kx + kd));
     }
-    if (a.zero) {
-        const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
-        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < a.nzero; i += nthr) a.zero[i] = 0.f;
-    }
     // transposed-read lane roles: lane 4q+p of its 16-lane group passes the address of pixel row q, channels 4p..4p+3 of the
     // group's 16 channels; groups 0,1 cover channels 0..15 / 16..31 of pixels 0..7 of the K-step, groups 2,3 pixels 8..15
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
@@ -1387,11 +1385,7 @@ static int sw_launch(const float* x, const float* xmax, const float* dconv, cons
     const size_t nW = (size_t)9 * Cin * Cout;
     float* slabs = (float*)workspace;
     float* bslabs = dbias ? slabs + (size_t)P * nW : nullptr;
-    // the slab sum meets in dw through atomics when it is split over blockIdx.y (the rule of wgrad_reduce_launch)
-    unsigned gx = dasr_cdiv(nW / 4, 256);
-    int ysplit = 1;
-    while (gx * ysplit < 512 && ysplit * 8 <= P) ysplit *= 2;
-    SplitWgradArgs a{xmax, dmax, x, dconv, slabs, bslabs, ysplit > 1 ? dw : nullptr, ysplit > 1 ? nW : 0, B, H, W, Cin, Cout, P, ntiles};
+    SplitWgradArgs a{xmax, dmax, x, dconv, slabs, bslabs, B, H, W, Cin, Cout, P, ntiles};
     const int th = sw_th(MT, NTW);
     const dim3 grid(groups, P);
     // fp16 x 2: the staged-split kernel (128 -> 128 424 -> 317 us, 64 -> 64 134 -> 107, 32 -> 128 at 512 x 640 1716 -> 1349, 32 -> 32
@@ -1407,7 +1401,7 @@ static int sw_launch(const float* x, const float* xmax, const float* dconv, cons
         else if (MT == 2 && NTW == 1) DASR_LAUNCH((k_conv3x3_wgrad_split2<2, 1>), grid, dim3(256), lds2, stream, a);
         else if (MT == 1 && NTW == 2) DASR_LAUNCH((k_conv3x3_wgrad_split2<1, 2>), grid, dim3(256), lds2, stream, a);
         else                          DASR_LAUNCH((k_conv3x3_wgrad_split2<1, 1>), grid, dim3(256), lds2, stream, a);
-        return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit > 1, bslabs, dbias, Cout);
+        return wgrad_reduce_launch(slabs, dw, nW, P, stream, bslabs, dbias, Cout);
     }
     const size_t lds = sizeof(float) * (size_t)((th + 2) * (SW_TW + 2) * 32 * MT + th * SW_TW * 32 * NTW);
     if (MT == 2 && NTW == 2)      DASR_LAUNCH((k_conv3x3_wgrad_split<2, 2, NP>), grid, dim3(256), lds, stream, a);
@@ -1415,7 +1409,7 @@ static int sw_launch(const float* x, const float* xmax, const float* dconv, cons
     else if (MT == 2 && NTW == 1) DASR_LAUNCH((k_conv3x3_wgrad_split<2, 1, NP>), grid, dim3(256), lds, stream, a);
     else if (MT == 1 && NTW == 2) DASR_LAUNCH((k_conv3x3_wgrad_split<1, 2, NP>), grid, dim3(256), lds, stream, a);
     else                          DASR_LAUNCH((k_conv3x3_wgrad_split<1, 1, NP>), grid, dim3(256), lds, stream, a);
-    return wgrad_reduce_launch(slabs, dw, nW, P, stream, ysplit > 1, bslabs, dbias, Cout);
+    return wgrad_reduce_launch(slabs, dw, nW, P, stream, bslabs, dbias, Cout);
 }
 extern "C" int dasr_conv3x3_wgrad_split(const float* x, const float* dconv, float* dw, float* dbias, void* workspace,
                                         size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream) {

@@ -55,6 +55,10 @@ __global__ void __launch_bounds__(256) k_weight_pack_fwd(const float* __restrict
 }
 
 // dv = (g/||v||) * (dw - v * <dw,v>/||v||^2) ; dg = <dw,v>/||v||
+// One workgroup per norm group.  NR = register slots per thread for the group's gathered dw (R <= 256 * NR): all loads of the
+// strided gather are issued before the first use and kept for the second pass (one latency instead of 2 * R / 256 of them);
+// NR = 0: any R, two passes over memory.
+template <int NR>
 __global__ void __launch_bounds__(256) k_weight_pack_bwd(const float* __restrict__ dw, const float* __restrict__ v,
                                                          const float* __restrict__ g,
                                                          const float* __restrict__ inv_norm, float* __restrict__ dv,
@@ -65,6 +69,32 @@ __global__ void __launch_bounds__(256) k_weight_pack_bwd(const float* __restrict
     int R = (transposed ? O : I) * KK;
     const float* vn = v + (size_t)n * R;
     float* dvn = dv + (size_t)n * R;
+    if (NR > 0) {
+        float d[NR > 0 ? NR : 1], vv[NR > 0 ? NR : 1];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int r = threadIdx.x + 256 * u;
+            d[u] = r < R ? dw[hwio_index(n, r, ldo, o_off, I, KK, transposed)] : 0.f;
+            vv[u] = r < R && g ? vn[r] : 0.f;
+        }
+        if (!g) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u)
+                if (threadIdx.x + 256 * u < R) dvn[threadIdx.x + 256 * u] = d[u];
+            return;
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) dot += d[u] * vv[u];
+        dot = block_sum_256(dot, red);
+        const float inv = inv_norm[n], gn = g[n];
+        if (threadIdx.x == 0) dg[n] = dot * inv;
+        const float c1 = gn * inv, c2 = gn * dot * inv * inv * inv;
+#pragma unroll
+        for (int u = 0; u < NR; ++u)
+            if (threadIdx.x + 256 * u < R) dvn[threadIdx.x + 256 * u] = c1 * d[u] - c2 * vv[u];
+        return;
+    }
     if (!g) {
         for (int r = threadIdx.x; r < R; r += 256) dvn[r] = dw[hwio_index(n, r, ldo, o_off, I, KK, transposed)];
         return;
@@ -106,7 +136,12 @@ extern "C" int dasr_weight_pack_bwd(const float* dw, const float* v, const float
     if (g) { DASR_CHECK_PTR(inv_norm); DASR_CHECK_PTR(dg); }
     DASR_CHECK_SHAPE(O > 0 && I > 0 && KH > 0 && KW > 0 && o_off >= 0 && ldo >= o_off + O);
     int groups = transposed ? I : O;
-    DASR_LAUNCH(k_weight_pack_bwd, dim3(groups), dim3(256), 0, stream, dw, v, g, inv_norm, dv, dg, O, I, KH * KW,
-                transposed, ldo, o_off);
+    const int R = (transposed ? O : I) * KH * KW;
+    if (R <= 256 * 5)       DASR_LAUNCH((k_weight_pack_bwd<5>), dim3(groups), dim3(256), 0, stream, dw, v, g, inv_norm, dv, dg, O, I,
+                                        KH * KW, transposed, ldo, o_off);      // (up to 128 channels x 3x3 = 1152)
+    else if (R <= 256 * 11) DASR_LAUNCH((k_weight_pack_bwd<11>), dim3(groups), dim3(256), 0, stream, dw, v, g, inv_norm, dv, dg, O, I,
+                                        KH * KW, transposed, ldo, o_off);      // (32 channels x 9x9 = 2592)
+    else                    DASR_LAUNCH((k_weight_pack_bwd<0>), dim3(groups), dim3(256), 0, stream, dw, v, g, inv_norm, dv, dg, O, I,
+                                        KH * KW, transposed, ldo, o_off);
     DASR_RETURN_LAUNCH_STATUS();
 }

@@ -39,7 +39,7 @@ def main():
         xm, ym = ops.absmax(x), ops.absmax(y)
         fl = 2.0 * 9 * ci * co * B * H * W
         keys = ("f32 fwd", "bf16x3 fwd", "fp16x2 fwd", "f32 dgrad", "bf16x3 dgrad", "fp16x2 dgrad", "f32 wgrad", "bf16x3 wgrad",
-                "fp16x2 wgrad", "fp16x2v1 wgrad", "fp16x2r4 fwd", "fp16x2r4 dgrad", "bf16x3 weights", "fp16x2 weights", "absmax x", "absmax y")
+                "fp16x2 wgrad", "fp16x2v1 wgrad", "fp16x2alt fwd", "fp16x2alt dgrad", "bf16x3 weights", "fp16x2 weights", "absmax x", "absmax y")
         r = {k: [] for k in keys}
         for _ in range(3):
             r["f32 fwd"].append(timeit(lambda: ops.conv2d_fwd(x, wp, bias)))
@@ -51,9 +51,9 @@ def main():
             r["f32 wgrad"].append(timeit(lambda: ops.conv2d_wgrad(x, y, (3, 3, ci, co))))
             r["bf16x3 wgrad"].append(timeit(lambda: ops.conv3x3_wgrad_split(x, y)))
             r["fp16x2 wgrad"].append(timeit(lambda: ops.conv3x3_wgrad_split2(x, xm, y, ym)))
-            ops.set_conv_bf16_impl(256)     # the four-wave form (four tile rows per wave) of the fp16 x 2 forward / dgrad
-            r["fp16x2r4 fwd"].append(timeit(lambda: ops.conv3x3_fwd_split2(x, xm, ws2, bias, co)))
-            r["fp16x2r4 dgrad"].append(timeit(lambda: ops.conv3x3_dgrad_split2(y, ym, ws2, x.shape)))
+            ops.set_conv_bf16_impl(256 + 512)   # the four-wave form (128 produced channels) / the chunk form (64) of the fp16 x 2 kernel
+            r["fp16x2alt fwd"].append(timeit(lambda: ops.conv3x3_fwd_split2(x, xm, ws2, bias, co)))
+            r["fp16x2alt dgrad"].append(timeit(lambda: ops.conv3x3_dgrad_split2(y, ym, ws2, x.shape)))
             ops.set_conv_bf16_impl(64)      # the first fp16 x 2 weight-gradient kernel (operands split per K-step)
             r["fp16x2v1 wgrad"].append(timeit(lambda: ops.conv3x3_wgrad_split2(x, xm, y, ym)))
             ops.set_conv_bf16_impl(0)
