@@ -41,6 +41,8 @@ def parse_args(argv=None):
                     help="A/B: 3 = three bf16 pieces / six products, 2 = two scaled fp16 pieces / three products (graph.SPLIT_PIECES)")
     ap.add_argument("--no-split", action="store_true",
                     help="A/B: fp32 path without the split-bf16 convolutions (graph.SPLIT_BF16 = False: exact-fp32 MFMA kernels)")
+    ap.add_argument("--no-prepack", action="store_true",
+                    help="A/B: one launch per packed kernel instead of the two multi-tensor launches per step (graph.PREPACK = False)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the forward-only batch-32 roofline pass")
     ap.add_argument("--wgrad-stream", action="store_true",
@@ -408,6 +410,9 @@ def main():
     if args.no_split:
         from dasr_amd import graph as _graph_mod3
         _graph_mod3.SPLIT_BF16 = False
+    if args.no_prepack:
+        from dasr_amd import graph as _graph_mod5
+        _graph_mod5.PREPACK = False
     if args.split_pieces is not None:
         from dasr_amd import graph as _graph_mod4
         _graph_mod4.SPLIT_PIECES = args.split_pieces

@@ -30,6 +30,7 @@ _CTYPES = {
     "const char*": ctypes.c_char_p, "const unsigned char*": ctypes.c_void_p, "unsigned char*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p,
     "const unsigned short*": ctypes.c_void_p, "unsigned short*": ctypes.c_void_p,      # bf16 bits
+    "const dasr_pack_job*": ctypes.c_void_p, "const dasr_split_job*": ctypes.c_void_p,  # job tables (structs below)
 }
 
 

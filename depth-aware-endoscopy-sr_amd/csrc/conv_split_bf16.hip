@@ -713,8 +713,8 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
 // NP = 3: three bf16 pieces; NP = 2: two fp16 pieces of w 2^k, k from *wmax (the max |w| of plane 0, dasr_absmax)
 __host__ __device__ static inline int sp_ntile(int N) { return (N % 128) == 0 ? 128 : ((N % 64) == 0 ? 64 : 32); }
 template <int NP>
-__global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__ w, unsigned short* __restrict__ ws, int Cin, int Cout,
-                                                       const float* __restrict__ wmax) {
+__device__ __forceinline__ void sp_split_weights(const float* __restrict__ w, unsigned short* __restrict__ ws, int Cin, int Cout,
+                                                 const float* __restrict__ wmax, int slab_first, int slab_step) {
     // one workgroup per (mode, slice, tap, chunk) slab: the index arithmetic is per workgroup, a thread walks (row, kk) pairs
     // (the first form decoded every element with five integer divisions: 17.6 us for 128 x 128, fifty-five times a step)
     const size_t per_mode = (size_t)9 * NP * Cin * Cout;
@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__
     }
     const int nslab0 = (Cout / sp_ntile(Cout)) * 9 * (Cin / 16);          // slabs of mode 0
     const int nslab1 = (Cin / sp_ntile(Cin)) * 9 * (Cout / 16);
-    for (int sl = blockIdx.x; sl < nslab0 + nslab1; sl += gridDim.x) {
+    for (int sl = slab_first; sl < nslab0 + nslab1; sl += slab_step) {
         const int mode = sl >= nslab0;
         const int q = sl - mode * nslab0;
         const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
@@ -760,6 +760,23 @@ __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__
             }
         }
     }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__ w, unsigned short* __restrict__ ws, int Cin, int Cout,
+                                                       const float* __restrict__ wmax) {
+    sp_split_weights<NP>(w, ws, Cin, Cout, wmax, blockIdx.x, gridDim.x);
+}
+// the fp16 x 2 images of every split convolution of a network in one launch: a job table in device memory (dasr.h:
+// dasr_split_job), one workgroup per slab of every job
+__global__ void __launch_bounds__(256) k_split_weights_multi(const dasr_split_job* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                  // the last job whose wg_begin <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].wg_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const dasr_split_job J = jobs[lo];
+    sp_split_weights<2>(J.w_packed, J.w_split, J.Cin, J.Cout, J.wmax, blockIdx.x - J.wg_begin, 1 << 30);
 }
 
 // ---- max |x| of a tensor as an amax buffer (dasr_common.h): one partial maximum per workgroup, no atomics, nothing to clear
@@ -832,8 +849,11 @@ int absmax_raise(const float* x, size_t n, float* amax, void* stream) {
     DASR_RETURN_LAUNCH_STATUS();
 }
 extern "C" int dasr_absmax(const float* x, size_t n, float* amax, void* stream) { return absmax_raise(x, n, amax, stream); }
-static unsigned sp_weight_slabs(int Cin, int Cout) {
-    unsigned n = (unsigned)((Cout / sp_ntile(Cout)) * 9 * (Cin / 16) + (Cin / sp_ntile(Cin)) * 9 * (Cout / 16));
+static unsigned sp_weight_slabs_all(int Cin, int Cout) {
+    return (unsigned)((Cout / sp_ntile(Cout)) * 9 * (Cin / 16) + (Cin / sp_ntile(Cin)) * 9 * (Cout / 16));
+}
+static unsigned sp_weight_slabs(int Cin, int Cout) {        // (the single-tensor launch: workgroups walk the slabs)
+    const unsigned n = sp_weight_slabs_all(Cin, Cout);
     return n > 2048 ? 2048 : n;
 }
 extern "C" size_t dasr_conv3x3_split_weights_bytes(int Cin, int Cout) {
@@ -857,6 +877,26 @@ extern "C" int dasr_conv3x3_split2_weights(const float* w_packed, const float* w
     DASR_CHECK_SHAPE(Cin > 0 && Cout > 0 && (Cin % 32) == 0 && (Cout % 32) == 0);
     DASR_LAUNCH((k_split_weights<2>), dim3(sp_weight_slabs(Cin, Cout)), dim3(256), 0, stream, w_packed, w_split, Cin, Cout,
                 wmax);
+    DASR_RETURN_LAUNCH_STATUS();
+}
+extern "C" int dasr_conv3x3_split2_weights_slabs(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0 || (Cin % 32) != 0 || (Cout % 32) != 0) return 0;
+    return (int)sp_weight_slabs_all(Cin, Cout);
+}
+extern "C" int dasr_conv3x3_split2_weights_multi(const dasr_split_job* jobs_host, const dasr_split_job* jobs_device, int njobs,
+                                                 void* stream) {
+    DASR_CHECK_PTR(jobs_host); DASR_CHECK_PTR(jobs_device);
+    DASR_CHECK_SHAPE(njobs > 0);
+    long long total = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const dasr_split_job& J = jobs_host[j];
+        DASR_CHECK_PTR(J.w_packed); DASR_CHECK_PTR(J.w_split); DASR_CHECK_PTR(J.wmax);
+        DASR_CHECK_SHAPE(J.Cin > 0 && J.Cout > 0 && (J.Cin % 32) == 0 && (J.Cout % 32) == 0);
+        DASR_CHECK_SHAPE(J.wg_begin == total);
+        total += sp_weight_slabs_all(J.Cin, J.Cout);
+        DASR_CHECK_SHAPE(total < (1ll << 30));
+    }
+    DASR_LAUNCH(k_split_weights_multi, dim3((unsigned)total), dim3(256), 0, stream, jobs_device, njobs);
     DASR_RETURN_LAUNCH_STATUS();
 }
 template <int NP>

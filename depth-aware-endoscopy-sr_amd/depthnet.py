@@ -140,6 +140,7 @@ class _DepthNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, act_dtype, inp, depth_map, depth_mask, region, *params):
         tape = Tape(enabled=True, act_dtype=act_dtype)
+        tape.prepack = net._prepack_for(inp.device, act_dtype)
         pvars = [Var(p.detach(), p.requires_grad, name) for name, p in zip(net._param_names, params)]
         P = {v.name: v for v in pvars}
         out = graph.depthnet_forward(tape, P, net.cfg, net._consts(inp.device), inp.detach().contiguous(),
@@ -247,6 +248,16 @@ class DepthNet(nn.Module):
                 "alpha_beta": Var(torch.full((1,), float(self.cfg["norm_beta"]), device=device)),
             }
         return self._const_cache[key]
+
+    def _prepack_for(self, device, act_dtype):
+        """This module's graph.Prepack for (device, activation dtype): the packed kernels of a training step, refilled in
+        two launches (the buffers live with the module; an nn.DataParallel replica gets its own)."""
+        if not hasattr(self, "_prepack"):
+            object.__setattr__(self, "_prepack", {})
+        key = (str(device), str(act_dtype))
+        if key not in self._prepack:
+            self._prepack[key] = graph.Prepack()
+        return self._prepack[key]
 
     def _resolve_params(self):
         """This module's (or this replica's) weight tensors, in ``_param_names`` order."""

@@ -79,13 +79,102 @@ def _folded(tape, key, tensors, make):
     return val
 
 
+# Training: the ~120 packed kernels of a step (weight_norm + HWIO pack), the max |w| and fp16 x 2 image of the ~55 split
+# convolutions and the 26 bias pairs in TWO launches at the start of the forward (dasr_weight_pack_multi,
+# dasr_conv3x3_split2_weights_multi) instead of ~300 small ones spread over it; False: one launch per tensor (A/B, tests).
+PREPACK = True
+
+
+class Prepack:
+    """The packed kernels of one network on one device.  The first training forward runs the per-tensor path and is recorded
+    (which parameters are packed how, which packed kernels get a split image); its output buffers are kept and become the
+    targets of the job tables.  Every later forward with the same signature (flags, input shape, parameter storage) refills
+    them in two launches before anything else is issued and hands them out by key."""
+
+    def __init__(self):
+        self.sig = None
+        self.ready = False
+        self.entries = {}
+        self.tables = None
+
+    @staticmethod
+    def signature(inp, act_dtype):
+        return (tuple(inp.shape), str(inp.device), str(act_dtype), SPLIT_BF16, SPLIT_WGRAD, SPLIT_PIECES, SPLIT_CONV9,
+                SPLIT_MIN_PIXELS, ENCODER_S2D)
+
+    def begin(self, P, sig):
+        """Start of a training forward: launch the tables if they fit this step, else start recording afresh."""
+        if self.ready and sig == self.sig and all(P[n].data.data_ptr() == ptr and P[n].data.shape == shp
+                                                  for n, ptr, shp in self.sources):
+            ops.weight_pack_multi(self.tables[0])
+            if self.tables[1] is not None:
+                ops.conv3x3_split2_weights_multi(self.tables[1])
+            return
+        self.sig, self.ready, self.entries, self.tables = sig, False, {}, None
+
+    def get(self, key):
+        return self.entries.get(key) if self.ready else None
+
+    def note(self, key, jobs, w, inv=None):
+        """Recording: ``jobs`` = [(v Var, g Var or None, transposed, o_off, plain)] that fill the buffer ``w``."""
+        if not self.ready and key is not None:
+            self.entries[key] = {"jobs": jobs, "w": w, "inv": inv, "split": None}
+
+    def note_split(self, key, split):
+        if not self.ready and key in self.entries:
+            self.entries[key]["split"] = split
+
+    def finish(self):
+        """End of the recorded forward: build the two job tables over the buffers that forward produced."""
+        if self.ready or not self.entries:
+            return
+        pj, sj, keep, sources = [], [], [], []
+        npk = nsl = 0
+        for e in self.entries.values():
+            w, am = e["w"], None
+            if e["split"] is not None:                 # (ws fp16 image, wmax) or ("c9", wmax): wmax now comes from the pack jobs
+                am = ops.amax_buffer(w)
+                if isinstance(e["split"][0], str):
+                    e["split"] = (e["split"][0], am)
+                else:
+                    ws = e["split"][0]
+                    job, n = ops.split_job(w, am, ws, nsl)
+                    sj.append(job)
+                    nsl += n
+                    e["split"] = (ws, am)
+            for v, g, transposed, o_off, plain in e["jobs"]:
+                job, n = ops.pack_job(v.data, g.data if g is not None else None, w, e["inv"], am, transposed, o_off, plain, npk)
+                pj.append(job)
+                npk += n
+                for t in (v, g):
+                    if t is not None:
+                        sources.append((t.name, t.data.data_ptr(), t.data.shape))
+            keep.append((w, e["inv"], am, e["split"]))
+            e["jobs"] = None
+        dev = keep[0][0].device
+        self.tables = (ops.JobTable(pj, dev, keep), ops.JobTable(sj, dev, keep) if sj else None)
+        self.sources = sources
+        self.ready = True
+
+
 def pack(tape, v, g=None, transposed=False, dtype=torch.float32):
     """weight_norm (if g) + OIHW -> HWIO; ``dtype`` bf16 for the trunk kernels of the mixed-precision path (fp32 master
     weights: the packed copy is rounded, the gradient comes back in fp32)."""
     srcs = [v.data] + ([g.data] if g is not None else [])
-    w, inv = _folded(tape, ("pack", v.name, str(dtype)) if v.name else None, srcs,
-                     lambda: ops.weight_pack(v.data, g.data if g is not None else None, transposed, dtype=dtype))
+    key = ("pack", v.name, str(dtype)) if v.name else None
+    pp = tape.prepack if (key is not None and (g is None or g.name)) else None
+    hit = pp.get(key) if pp is not None else None
+    if hit is not None:
+        w, inv = hit["w"], hit["inv"]
+    else:
+        w, inv = _folded(tape, key, srcs,
+                         lambda: ops.weight_pack(v.data, g.data if g is not None else None, transposed, dtype=dtype))
+        if pp is not None:
+            pp.note(key, [(v, g, transposed, 0, False)], w, inv)
     out = Var(w, v.requires_grad or (g is not None and g.requires_grad))
+    if pp is not None:
+        out.pack = key
+        out.split = hit["split"] if hit is not None else None
 
     def bwd():
         if out.grad is None:
@@ -114,8 +203,19 @@ def pack_pair(tape, va, vb, dtype=torch.float32):
         ops.weight_pack(vb.data, None, False, out=w, o_off=Oa)
         return w
 
-    w = _folded(tape, ("pair", va.name, str(dtype)) if va.name else None, [va.data, vb.data], make)
+    key = ("pair", va.name, str(dtype)) if va.name else None
+    pp = tape.prepack if (key is not None and vb.name) else None
+    hit = pp.get(key) if pp is not None else None
+    if hit is not None:
+        w = hit["w"]
+    else:
+        w = _folded(tape, key, [va.data, vb.data], make)
+        if pp is not None:
+            pp.note(key, [(va, None, False, 0, False), (vb, None, False, Oa, False)], w)
     out = Var(w, va.requires_grad or vb.requires_grad)
+    if pp is not None:
+        out.pack = key
+        out.split = hit["split"] if hit is not None else None
 
     def bwd():
         if out.grad is None:
@@ -142,7 +242,15 @@ def bias_pair(tape, ba, bb):
         ops.copy_(buf[na:], bb.data)
         return buf
 
-    buf = _folded(tape, ("bias", ba.name) if ba.name else None, [ba.data, bb.data], make)
+    key = ("bias", ba.name) if ba.name else None
+    pp = tape.prepack if (key is not None and bb.name and ba.data.dtype == torch.float32) else None
+    hit = pp.get(key) if pp is not None else None
+    if hit is not None:
+        buf = hit["w"]
+    else:
+        buf = _folded(tape, key, [ba.data, bb.data], make)
+        if pp is not None:
+            pp.note(key, [(ba, None, False, 0, True), (bb, None, False, na, True)], buf)
     out = Var(buf, ba.requires_grad or bb.requires_grad)
 
     def bwd():
@@ -213,6 +321,8 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
             w.split = _folded(tape, ("split%d" % SPLIT_PIECES, "@%x" % w.data.data_ptr()), [w.data],
                               (lambda: ops.conv3x3_split2_weights(w.data)) if SPLIT_PIECES == 2 else
                               (lambda: ops.conv3x3_split_weights(w.data)))
+            if w.pack is not None and isinstance(w.split, tuple):
+                tape.prepack.note_split(w.pack, w.split)
         if isinstance(w.split, tuple):
             y = ops.conv3x3_fwd_split2(x.data, _amax(x), w.split, bias.data if bias is not None else None, w.data.shape[4],
                                        residual.data if residual is not None else None, act, ps_r,
@@ -227,6 +337,8 @@ def conv(tape, x, w, bias=None, *, stride=1, pad=1, transposed=False, act=ops.AC
         # the 9x9 output convolution, same scheme (csrc/conv9_split.hip): the kernel is split when it is staged, only its max |.| is needed
         if w.split is None:
             w.split = ("c9", _folded(tape, ("c9max", "@%x" % w.data.data_ptr()), [w.data], lambda: ops.absmax(w.data[0])))
+            if w.pack is not None:
+                tape.prepack.note_split(w.pack, w.split)
         y = ops.conv9_fwd_split2(x.data, _amax(x), w.data, w.split[1], bias.data if bias is not None else None)
     else:
         # (the mask layer 1 -> 2C feeds the gamma_o|beta_o convolution, the encoder's first layer the head: their kernel
@@ -736,6 +848,11 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=No
     plan = block_plan(cfg)
     nb, scale = cfg["nb"], cfg["scale"]
     B = inp.shape[0]
+    if tape.prepack is not None:
+        if PREPACK and tape.enabled:
+            tape.prepack.begin(P, Prepack.signature(inp, tape.act_dtype))
+        else:
+            tape.prepack = None
     x0 = Var(ops.nchw_to_nhwc(inp))
     dm = Var(depth_map.reshape(B, depth_map.shape[2], depth_map.shape[3], 1))   # [B,1,h,w] == [B,h,w,1]
     L = ops.ACT_LRELU
@@ -805,6 +922,8 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=No
     y = conv(tape, fea, pack(tape, P["conv_output.weight"]), P["conv_output.bias"], pad=4, side_wgrad=True)     # :948
     lo, hi = cfg["out_min"], cfg["out_max"]
     out = Var(ops.clamp_to_nchw(y.data, lo, hi), True)                                          # :950
+    if tape.prepack is not None:
+        tape.prepack.finish()
 
     def bwd():
         if out.grad is None:

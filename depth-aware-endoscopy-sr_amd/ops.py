@@ -6,6 +6,8 @@ computation is a call into libdasr_hip.so.  Activations are NHWC ``[B,H,W,C]``, 
 points (mixed-precision path: bf16 activations and trunk kernels, fp32 parameters / statistics /
 accumulators) - the dtype of the tensors passed in decides, nothing is converted silently.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -271,6 +273,61 @@ def weight_pack(v, g, transposed=False, out=None, o_off=0, dtype=torch.float32):
         _call("dasr_weight_pack_fwd", _p(v), _p(g, True), _p(out), _p(inv, True), O, I, KH, KW, int(transposed), ldo,
               int(o_off))
     return out, inv
+
+
+class PackJob(ctypes.Structure):
+    """include/dasr.h: dasr_pack_job."""
+    _fields_ = [("v", ctypes.c_void_p), ("g", ctypes.c_void_p), ("w", ctypes.c_void_p), ("inv_norm", ctypes.c_void_p),
+                ("amax", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in
+                                              ("O", "I", "KK", "transposed", "ldo", "o_off", "bf16", "plain", "wg_begin", "reserved")]
+
+
+class SplitJob(ctypes.Structure):
+    """include/dasr.h: dasr_split_job."""
+    _fields_ = [("w_packed", ctypes.c_void_p), ("wmax", ctypes.c_void_p), ("w_split", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int) for n in ("Cin", "Cout", "wg_begin", "reserved")]
+
+
+class JobTable:
+    """A job table of one multi-tensor launch: the ctypes array (host copy) and its image in device memory, kept together
+    with the tensors the jobs point at."""
+
+    def __init__(self, jobs, device, keep):
+        self.n = len(jobs)
+        self.host = (type(jobs[0]) * self.n)(*jobs)
+        self.dev = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(device)
+        self.keep = keep
+
+
+def pack_job(v, g, w, inv, amax, transposed, o_off, plain, wg_begin):
+    """One dasr_weight_pack_fwd call as a table entry (``w``: the packed buffer (2, KH, KW, I, ldo), or a flat buffer of
+    ldo floats when ``plain``: a bias vector placed at o_off)."""
+    if plain:
+        O, I, KK, ldo = v.numel(), 1, 1, w.numel()
+    else:
+        if transposed:
+            I, O, KH, KW = v.shape
+        else:
+            O, I, KH, KW = v.shape
+        KK, ldo = KH * KW, w.shape[4]
+    bf = w.dtype == BF16
+    return PackJob(_p(v), _p(g, True), _lib.ptr(w, False, w.dtype), _p(inv, True), _p(amax, True), O, I, KK, int(transposed), ldo,
+                   int(o_off), int(bf), int(plain), int(wg_begin), 0), (I if transposed else O)
+
+
+def weight_pack_multi(table):
+    _call("dasr_weight_pack_multi", ctypes.addressof(table.host), table.dev.data_ptr(), table.n)
+
+
+def split_job(w, wmax, ws, wg_begin):
+    KH, KW, Cin, Cout = _wdims(w)
+    assert (KH, KW) == (3, 3) and w.dtype == torch.float32
+    return (SplitJob(_p(w), _p(wmax), _lib.ptr(ws, False, torch.float16), Cin, Cout, int(wg_begin), 0),
+            int(_lib.get().dasr_conv3x3_split2_weights_slabs(Cin, Cout)))
+
+
+def conv3x3_split2_weights_multi(table):
+    _call("dasr_conv3x3_split2_weights_multi", ctypes.addressof(table.host), table.dev.data_ptr(), table.n)
 
 
 def weight_pack_bwd(dw, v, g, inv, transposed=False, o_off=0):

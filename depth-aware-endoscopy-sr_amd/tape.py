@@ -12,7 +12,7 @@ from . import ops
 class Var:
     """A device tensor plus its gradient slot."""
     __slots__ = ("data", "grad", "requires_grad", "name", "uses", "epilogue", "grad_is_preact", "event",
-                 "grad_event", "stats", "split", "amax")
+                 "grad_event", "stats", "split", "amax", "pack")
 
     def __init__(self, data, requires_grad=False, name=None):
         self.data = data
@@ -27,6 +27,7 @@ class Var:
         self.stats = None            # (mean, var) per (b, c) when the producing conv computed them in its epilogue
         self.split = None            # packed fp32 kernels: their bf16 three-piece / fp16 two-piece image (graph.SPLIT_BF16), built at first use
         self.amax = None             # (stream, max |data| device scalar) for the fp16 x 2 split scheme (graph._amax)
+        self.pack = None             # packed kernels of a training step: their key in the step's graph.Prepack
 
     @property
     def shape(self):
@@ -45,6 +46,7 @@ class Tape:
         self._stream = None
         self.side_streams = []
         self.fold_cache = None      # inference only: {param name: (versions, packed tensor)}, see graph._folded
+        self.prepack = None         # training: the network's graph.Prepack (every packed kernel of the step in two launches)
         self.marks = []             # node counts at which the forward plan called mark(): gradient-bucket boundaries
         self.on_mark = None         # called during backward() each time the tape has unwound below a mark
 

@@ -77,6 +77,22 @@ int dasr_resize_nearest_u8(const unsigned char* src, unsigned char* dst, int B, 
  */
 int dasr_weight_pack_fwd(const float* v, const float* g, float* w_hwio, float* inv_norm, int O, int I, int KH, int KW,
                          int transposed, int ldo, int o_off, void* stream);
+/* Every kernel of a network in one launch (a training step re-packs ~120 weight tensors: one launch instead of ~120).
+ * One job = one dasr_weight_pack_fwd call; `jobs_host` and `jobs_device` hold the same njobs entries in host / device memory
+ * (the host copy is validated, the kernel reads the device copy; the caller keeps both alive until the launch has run).
+ *   w, bf16   : the packed kernel, float (bf16 = 0) or bf16 bits (bf16 = 1, as dasr_weight_pack_fwd_bf16)
+ *   KK        : KH * KW
+ *   amax      : NULL, or an amax buffer (DASR_AMAX_FLOATS floats, see "amax buffers" below) of the packed kernel: the job's norm
+ *               groups leave their max |w| in parts o_off .. o_off + O - 1 and the part count ldo (so that jobs sharing one
+ *               packed kernel fill one buffer) - what dasr_conv3x3_split2_weights / the 9x9 split kernels take as wmax, without
+ *               a dasr_absmax pass; conv kernels only (transposed = 0), ldo <= DASR_AMAX_MAX_PARTS
+ *   plain     : 1 = write the HWIO half only (two bias vectors side by side: O = n, I = KK = 1)
+ *   wg_begin  : sum of the norm-group counts (O, or I when transposed) of the jobs before this one */
+typedef struct dasr_pack_job {
+    const float* v; const float* g; void* w; float* inv_norm; float* amax;
+    int O, I, KK, transposed, ldo, o_off, bf16, plain, wg_begin, reserved;
+} dasr_pack_job;
+int dasr_weight_pack_multi(const dasr_pack_job* jobs_host, const dasr_pack_job* jobs_device, int njobs, void* stream);
 /* given dW (HWIO): dv (layout of v) and dg ([O or I]); g == NULL: dv = unpacked dW, dg untouched. */
 int dasr_weight_pack_bwd(const float* dw_hwio, const float* v, const float* g, const float* inv_norm, float* dv,
                          float* dg, int O, int I, int KH, int KW, int transposed, int ldo, int o_off, void* stream);
@@ -191,6 +207,14 @@ int dasr_absmax(const float* x, size_t n, float* amax, void* stream);
 size_t dasr_conv3x3_split2_weights_bytes(int Cin, int Cout);
 int dasr_conv3x3_split2_weights(const float* w_packed, const float* wmax, unsigned short* w_split, int Cin, int Cout,
                                 void* stream);
+/* ... of every split convolution of a network in one launch (as dasr_weight_pack_multi: host and device copy of the job table;
+ * wg_begin = sum of dasr_conv3x3_split2_weights_slabs(Cin, Cout) of the jobs before) */
+typedef struct dasr_split_job {
+    const float* w_packed; const float* wmax; unsigned short* w_split;
+    int Cin, Cout, wg_begin, reserved;
+} dasr_split_job;
+int dasr_conv3x3_split2_weights_slabs(int Cin, int Cout);
+int dasr_conv3x3_split2_weights_multi(const dasr_split_job* jobs_host, const dasr_split_job* jobs_device, int njobs, void* stream);
 int dasr_conv3x3_fwd_split2(const float* x, const float* xmax, const unsigned short* w_split, const float* wmax,
                             const float* bias, const float* residual, float* y, float* y_amax, int B, int H, int W, int Cin,
                             int Cout, int act, int ps_r, void* stream);

@@ -5,6 +5,7 @@ import math
 import os
 
 import numpy as np
+import ctypes
 import torch
 import torch.nn.functional as F
 
@@ -1307,12 +1308,12 @@ def check_fused_amax_net(device, case_name="x8_nb4"):
     case = [c for c in DEPTHNET_CASES if c["name"] == case_name][0]
     net, cfg = build_net(case, device)
     lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, case["B"], case["H"], case["W"], cfg["scale"])]
-    old = graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.FUSE_AMAX
+    old = graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.FUSE_AMAX, graph.PREPACK
     calls = {}
     orig_absmax = ops.absmax
     res = {}
     try:
-        graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES = 0, 2
+        graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.PREPACK = 0, 2, False     # (per-tensor weight maxima in both runs)
         for fused in (True, False):
             graph.FUSE_AMAX = fused
             n = [0]
@@ -1330,7 +1331,7 @@ def check_fused_amax_net(device, case_name="x8_nb4"):
             calls[fused] = n[0]
     finally:
         ops.absmax = orig_absmax
-        graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.FUSE_AMAX = old
+        graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.FUSE_AMAX, graph.PREPACK = old
     assert torch.equal(res[True][0], res[False][0]), "forward differs between fused and separate maxima"
     # (the GPU's weight / bias gradient reductions end in float atomics: two identical runs differ in the last bits there)
     for k, gten in res[False][1].items():
@@ -1341,6 +1342,121 @@ def check_fused_amax_net(device, case_name="x8_nb4"):
             assert d <= 2e-5 * max(gten.double().norm().item(), 1e-30) or any(z in k for z in ZERO_GRAD_KEYS), ("gradient differs", k, d)
     assert calls[True] * 2 <= calls[False], calls          # (what is left: the kernels' own maxima, a few unfused producers)
     return dict(absmax_passes_fused=calls[True], absmax_passes_separate=calls[False])
+
+
+def check_prepack_ops(device, seed=9):
+    """dasr_weight_pack_multi / dasr_conv3x3_split2_weights_multi against the per-tensor entry points they batch: a
+    weight-normed kernel, a transposed one, two plain kernels side by side in one packed buffer, a bf16 packed kernel and a
+    bias pair in ONE launch - bit-identical buffers, 1/||v|| vectors, and (through the amax buffers the jobs fill) the same
+    max |w| and fp16 x 2 images as dasr_absmax + dasr_conv3x3_split2_weights."""
+    gen = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=gen).to(device)
+    v1, g1 = rn(64, 32, 3, 3), rn(64, 1, 1, 1).abs() + 0.5
+    v2, g2 = rn(32, 48, 3, 3), rn(32, 1, 1, 1).abs() + 0.5            # ConvTranspose2d layout [I][O][KH][KW]
+    va, vb = rn(64, 128, 3, 3) * 0.05, rn(64, 128, 3, 3) * 3.0
+    v3, g3 = rn(32, 32, 3, 3), rn(32, 1, 1, 1).abs() + 0.5
+    v9 = rn(3, 32, 9, 9)
+    ba, bb = rn(64), rn(64)
+    # per-tensor reference
+    w1, i1 = ops.weight_pack(v1, g1)
+    w2, i2 = ops.weight_pack(v2, g2, transposed=True)
+    wp = ops.empty((2, 3, 3, 128, 128), va)
+    ops.weight_pack(va, None, False, out=wp, o_off=0)
+    ops.weight_pack(vb, None, False, out=wp, o_off=64)
+    w3, i3 = ops.weight_pack(v3, g3, dtype=torch.bfloat16)
+    w9, _ = ops.weight_pack(v9, None)
+    s1, sp = ops.conv3x3_split2_weights(w1), ops.conv3x3_split2_weights(wp)
+    m9 = ops.amax_value(ops.absmax(w9[0]))
+    # one launch
+    W1, W2, WP, W3, W9 = (torch.full_like(t, 7.0) for t in (w1, w2, wp, w3, w9))
+    I1, I2, I3 = (torch.full_like(t, 7.0) for t in (i1, i2, i3))
+    BP = torch.full((128,), 7.0, device=device)
+    A1, AP, A9 = ops.amax_buffer(v1), ops.amax_buffer(v1), ops.amax_buffer(v1)
+    jobs, n = [], 0
+    for args in ((v1, g1, W1, I1, A1, False, 0, False), (v2, g2, W2, I2, None, True, 0, False),
+                 (va, None, WP, None, AP, False, 0, False), (vb, None, WP, None, AP, False, 64, False),
+                 (v3, g3, W3, I3, None, False, 0, False), (ba, None, BP, None, None, False, 0, True),
+                 (bb, None, BP, None, None, False, 64, True), (v9, None, W9, None, A9, False, 0, False)):
+        job, k = ops.pack_job(*args, n)
+        jobs.append(job)
+        n += k
+    assert ctypes.sizeof(ops.PackJob) == 80 and ctypes.sizeof(ops.SplitJob) == 40
+    ops.weight_pack_multi(ops.JobTable(jobs, v1.device, None))
+    for a, b, nm in ((w1, W1, "wn"), (w2, W2, "transposed"), (wp, WP, "pair"), (w3, W3, "bf16"), (w9, W9, "9x9"), (i1, I1, "inv"),
+                     (i2, I2, "inv t"), (i3, I3, "inv bf16"), (torch.cat([ba, bb]), BP, "bias pair")):
+        assert torch.equal(a, b), nm
+    assert ops.amax_value(A1) == ops.amax_value(s1[1]) and ops.amax_value(AP) == ops.amax_value(sp[1]) and ops.amax_value(A9) == m9
+    S1, SP = torch.zeros_like(s1[0]), torch.zeros_like(sp[0])
+    j1, k1 = ops.split_job(W1, A1, S1, 0)
+    j2, _ = ops.split_job(WP, AP, SP, k1)
+    ops.conv3x3_split2_weights_multi(ops.JobTable([j1, j2], v1.device, None))
+    assert torch.equal(S1, s1[0]) and torch.equal(SP, sp[0])
+    # a table whose wg_begin does not add up is refused before anything is launched
+    bad, _ = ops.pack_job(v1, g1, W1, I1, A1, False, 0, False, 5)
+    try:
+        ops.weight_pack_multi(ops.JobTable([bad], v1.device, None))
+        raise AssertionError("an inconsistent job table was accepted")
+    except RuntimeError:
+        pass
+    return dict(jobs=len(jobs), workgroups=n)
+
+
+def check_prepack_net(device, case_name="x8_nb4", steps=3):
+    """graph.PREPACK: the packed kernels of a training step refilled in two launches from the second step on.  Three steps (every
+    parameter changed in place in between, so that every pack sees new weights) with and without: the same outputs and gradients to the bit
+    on the emulator (GPU: forward to the bit, gradients to reduction noise), and no per-tensor pack / split / absmax-of-weights
+    call once the tables are ready."""
+    from dasr_amd import graph
+    case = [c for c in DEPTHNET_CASES if c["name"] == case_name][0]
+    old = graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.PREPACK
+    counted = ("weight_pack", "conv3x3_split2_weights", "copy_")
+    orig = {k: getattr(ops, k) for k in counted}
+    res, calls = {}, {}
+    try:
+        graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES = 0, 2
+        for pre in (True, False):
+            graph.PREPACK = pre
+            net, cfg = build_net(case, device)
+            lq, gt, dm, mk = [t.to(device) for t in synth.closed_form_batch(0, case["B"], case["H"], case["W"], cfg["scale"])]
+            res[pre], calls[pre] = [], []
+            for step in range(steps):
+                n = {k: 0 for k in counted}
+                for k in counted:
+                    def wrapped(*a, _k=k, _n=n, **kw):
+                        _n[_k] += 1
+                        return orig[_k](*a, **kw)
+                    setattr(ops, k, wrapped)
+                net.zero_grad(set_to_none=True)
+                sr = net(lq, dm, mk)
+                wgt = torch.cos(torch.arange(sr.numel(), dtype=torch.float32) * 0.013).reshape(sr.shape).to(device)
+                (sr * wgt).sum().backward()
+                grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+                res[pre].append((sr.detach().clone(), grads))
+                calls[pre].append(dict(n))
+                with torch.no_grad():               # (not along the gradients: on the GPU their last bits vary from run to run)
+                    for i, (k, p) in enumerate(net.named_parameters()):
+                        bump = torch.cos(torch.arange(p.numel(), dtype=torch.float32) * 0.37 + i + step).reshape(p.shape).to(device)
+                        p.add_(bump * p.abs().max(), alpha=2e-3)
+            if pre:
+                plans = list(net._prepack.values())
+                assert len(plans) == 1 and plans[0].ready and plans[0].tables[1] is not None
+    finally:
+        for k in counted:
+            setattr(ops, k, orig[k])
+        graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.PREPACK = old
+    for step in range(steps):
+        assert torch.equal(res[True][step][0], res[False][step][0]), ("forward differs", step)
+        for k, gten in res[False][step][1].items():
+            if device == "cpu":
+                assert torch.equal(res[True][step][1][k], gten), ("gradient differs", step, k)
+            else:
+                d = (res[True][step][1][k] - gten).double().norm().item()
+                assert d <= 2e-5 * max(gten.double().norm().item(), 1e-30) or any(z in k for z in ZERO_GRAD_KEYS), ("gradient differs", step, k, d)
+    assert calls[True][0] == calls[False][0], (calls[True][0], calls[False][0])        # the recorded step IS the per-tensor path
+    assert all(c["weight_pack"] == 0 and c["conv3x3_split2_weights"] == 0 and c["copy_"] <= calls[False][0]["copy_"] - 4
+               for c in calls[True][1:]), calls[True]                                   # (copy_: the bias pairs are jobs too)
+    assert all(c["weight_pack"] > 20 and c["conv3x3_split2_weights"] > 5 for c in calls[False]), calls[False]
+    return dict(per_tensor_calls=calls[False][0], prepacked_calls=calls[True][-1])
 
 
 def check_split_conv(device, seed=5, pieces=3):

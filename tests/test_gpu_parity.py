@@ -49,6 +49,14 @@ def test_fused_amax_net():
     print(pc.check_fused_amax_net("cuda"))
 
 
+def test_prepack_ops():
+    print(pc.check_prepack_ops("cuda"))
+
+
+def test_prepack_net():
+    print(pc.check_prepack_net("cuda"))
+
+
 def test_ssim_kernel():
     print(pc.check_ssim_kernel("cuda"))
 

@@ -34,6 +34,14 @@ def test_fused_amax_net(emu):
     print(pc.check_fused_amax_net("cpu"))
 
 
+def test_prepack_ops(emu):
+    print(pc.check_prepack_ops("cpu"))
+
+
+def test_prepack_net(emu):
+    print(pc.check_prepack_net("cpu", "x2_nb4", steps=2))
+
+
 def test_pixel_shuffle_bit_exact(emu):
     pc.check_pixel_shuffle_bit_exact("cpu")
 
