@@ -241,14 +241,14 @@ __device__ __forceinline__ f16x8 sp_frag(const char* px, int lh, int key, int pl
 template <int NT, int NP, int RW = 2>
 __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[RW][NT], const ConvSplitArgs& a, char* const scr, const float* sBias,
                                             const float inv, const int x0, const int y0, const int n0, const int bb,
-                                            const int wv, const int lane, const int li, const int lh, float& om) {
+                                            const int rbase, const int lane, const int li, const int lh, float& om) {
     const int wvalid = a.W - x0;
     const bool is_relu = a.act == DASR_ACT_RELU;
     const float slope = a.act == DASR_ACT_LRELU02 ? 0.2f : 1.f;
     const bool has_act = a.act != DASR_ACT_NONE;
 #pragma unroll
     for (int m = 0; m < RW; ++m) {
-        const int gy = y0 + RW * wv + m;
+        const int gy = y0 + rbase + m;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -321,10 +321,16 @@ __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[RW][NT], const ConvSpl
 // RW = tile rows per wave.  2: eight waves (two per SIMD).  4 (fp16 x 2, 128 produced channels): FOUR waves, one per SIMD, each
 // with 4 x 4 accumulator tiles (256 registers: the unified 512-register file of a single-wave SIMD) - a kernel fragment read
 // from LDS then serves four tile rows instead of two (64 KB instead of 96 KB of operand reads per tap and CU).
-template <int NT, int NP, int RW = 2>
+// CW = 2 (fp16 x 2): the eight waves as 4 row groups x 2 channel halves - a wave owns FOUR tile rows of HALF the produced
+// channels (the same 128 / 64 accumulator registers) - and a K-step is a kernel COLUMN: the six halo rows a wave's four tile
+// rows meet under the three taps of a column are read once (12 KB) instead of once per tap and row pair (3 x 4 KB for half the
+// rows), and each kernel fragment serves four rows: 24 KB of operand reads per wave and step (72 MFMAs) instead of 36 KB.
+template <int NT, int NP, int RW = 2, int CW = 1>
 __global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_split(ConvSplitArgs a) {
     DASR_DYN_SMEM(smem);
     typedef SpFrag<NP> F;
+    static_assert(CW == 1 || (CW == 2 && NP == 2 && RW == 2 && (NT % 2) == 0), "channel halves: fp16 x 2, eight waves");
+    constexpr int MR = RW * CW, NW = NT / CW;           // a wave's tile rows / 32-channel tiles
     constexpr int NWV = SP_TH / RW, NTHR = 64 * NWV, NHP = SP_HBYTES / (16 * NTHR);
     constexpr int NTILE = 32 * NT, PIECE = NTILE * 32, SLAB = NP * PIECE;    // bytes: one 16-bit piece [NTILE][16], a K-step's NP
     constexpr int WP = SLAB / 16;                                            // DMA pieces per slice: 768 / 384 (NP = 2: 512 / 256)
@@ -343,6 +349,7 @@ __global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_
     float* const sRed = sBias + a.Cout;                 // [32]: the two maxima's per-wave parts, later the ymax scratch
     const int tid = threadIdx.x, lane = tid & 63, wv = DASR_UNIFORM((int)(tid >> 6));
     const int li = lane & 31, lh = lane >> 5;
+    const int wr = wv / CW, wc = wv % CW;
     // DMA pieces of a kernel slice per thread, NP = 3: NT = 4: 768 = 512 + 256 (waves 0-3 two, waves 4-7 one); NT = 2: 384
     // (waves 0-5 one, waves 6-7 none).  NP = 2: NT = 4: 512 (every wave one); NT = 2: 256 (waves 0-3).  A wave's count is static.
     const int nwq = WQ + (wv < WR ? 1 : 0);
@@ -405,7 +412,7 @@ __global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_
     auto w_issue = [&](int cc, int st, int fn0) {
 #pragma unroll
         for (int j = 0; j < TPS; ++j) {
-            const int tap = TPS * st + j;
+            const int tap = CW == 2 ? 3 * j + st : TPS * st + j;      // (CW = 2: step st = kernel column st, its three rows)
             const char* src = (const char*)a.ws + (size_t)(((fn0 / NTILE) * 9 + tap) * NC + cc) * SLAB + 16 * tid;
             const dasr_lds_addr_t dst = ldsW + ((st % R) * TPS + j) * SLAB;
 #pragma unroll
@@ -420,8 +427,8 @@ __global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_
     auto halo_first = [](int st) { return TPS == 1 ? st : (st == 0 ? 0 : (st == 1 ? HC0 : NHP)); };
     auto halo_count = [](int st) { return TPS == 1 ? (st < NHP ? 1 : 0) : (st == 0 ? HC0 : (st == 1 ? NHP - HC0 : 0)); };
 
-    const int Pl = RW * wv * SP_HW + li;
-    const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4);
+    const int Pl = MR * wr * SP_HW + li;
+    const int boff = li * 32 + ((lh ^ ((li >> 3) & 1)) << 4) + wc * NW * 1024;
 
     int par = 0;
     float om = 0.f;                                     // running max |y| of this lane (a.ymax)
@@ -437,15 +444,15 @@ __global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_
         int nx0 = x0, ny0 = y0, nn0 = n0, nb = bb;
         if (has_next) decode(nitem, nx0, ny0, nn0, nb);
 
-        f32x16 acc[RW][NT];
+        f32x16 acc[MR][NW];
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NW; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 bv = *(const float4*)(sBias + n0 + 32 * n + 8 * g + 4 * lh);
                 if (NP == 2) bv = make_float4(0.f, 0.f, 0.f, 0.f);         // (scaled sums: the bias joins in the epilogue)
 #pragma unroll
-                for (int m = 0; m < RW; ++m) {
+                for (int m = 0; m < MR; ++m) {
                     acc[m][n][4 * g] = bv.x; acc[m][n][4 * g + 1] = bv.y;
                     acc[m][n][4 * g + 2] = bv.z; acc[m][n][4 * g + 3] = bv.w;
                 }
@@ -476,6 +483,34 @@ __global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_
                 for (int u = 0; u < halo_count(st); ++u) halo_issue(halo_first(st) + u, fcc, par ^ 1);
                 if (st + D < NS) w_issue(cc, st + D, n0);
                 else             w_issue(fcc, st + D - NS, last ? nn0 : n0);
+                if constexpr (CW == 2) {
+                    int Pq = Pl;
+#ifndef DASR_HIPEMU
+                    asm volatile("" : "+v"(Pq));
+#endif
+                    typename F::type A6[MR + 2][NP];
+#pragma unroll
+                    for (int r = 0; r < MR + 2; ++r) {
+                        const int P = Pq + r * SP_HW + st;
+                        const int key = (P >> 2) & 3;
+                        A6[r][0] = sp_frag(hb + P * 64, lh, key, 0);
+                        A6[r][1] = sp_frag(hb + P * 64, lh, key, 1);
+                    }
+                    DASR_SETPRIO(1);
+#pragma unroll
+                    for (int tj = 0; tj < 3; ++tj) {
+                        const char* const wb = sW + ((st % R) * TPS + tj) * SLAB + boff;
+#pragma unroll
+                        for (int n = 0; n < NW; ++n) {
+                            typename F::type Bw[NP];
+#pragma unroll
+                            for (int j = 0; j < NP; ++j) Bw[j] = *(const typename F::type*)(wb + j * PIECE + n * 1024);
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) acc[m][n] = F::mma(Bw, A6[m + tj], acc[m][n]);
+                        }
+                    }
+                    DASR_SETPRIO(0);
+                } else {
 #pragma unroll
                 for (int tj = 0; tj < TPS; ++tj) {
                 const int tap = TPS * st + tj;
@@ -511,6 +546,7 @@ __global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_
                 }
                 DASR_SETPRIO(0);
                 }
+                }
             }
             par ^= 1;
         }
@@ -519,7 +555,7 @@ __global__ void __launch_bounds__(64 * (SP_TH / RW), RW == 4 ? 1 : 2) k_conv3x3_
         // accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue
         DASR_RAW_BARRIER();
         char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
-        sp_epilogue<NT, NP, RW>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh, om);
+        sp_epilogue<NW, NP, MR>(acc, a, scr, sBias, sc.inv, x0, y0, n0 + 32 * NW * wc, bb, MR * wr, lane, li, lh, om);
         if (!has_next) break;
         item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
     }
@@ -698,7 +734,7 @@ __global__ void __launch_bounds__(SP_NTHR, 2) k_conv3x3_split_n32(ConvSplitArgs 
         // accumulate and the PixelShuffle(2) store as in conv_mfma.hip's epilogue
         DASR_RAW_BARRIER();
         char* const scr = sH + (par ^ 1) * SP_HBYTES + wv * (32 * SP_EPITCH);
-        sp_epilogue<NT, NP>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, wv, lane, li, lh, om);
+        sp_epilogue<NT, NP>(acc, a, scr, sBias, sc.inv, x0, y0, n0, bb, 2 * wv, lane, li, lh, om);
         if (!has_next) break;
         item = nitem; x0 = nx0; y0 = ny0; n0 = nn0; bb = nb;
     }
@@ -918,6 +954,13 @@ static int sp_launch(ConvSplitArgs& a, void* stream) {
     // (impl + 256, A/B: the four-wave form - four tile rows per wave - of the fp16 x 2 kernel at 128 produced channels)
     if (NT == 4 && NP == 2 && (dasr_get_conv_bf16_impl() & 256) != 0)
         DASR_LAUNCH((k_conv3x3_split<4, 2, 4>), grid, dim3(256), lds, stream, a);
+    // fp16 x 2, 128 produced channels: the channel-halves / kernel-column form (128 -> 128 forward 284 -> 279 us, 64 -> 256 286 ->
+    // 278, 32 -> 128 at 512 x 640 1342 -> 1295; dgrads unchanged); at 64 produced channels it is no faster (64 -> 32 at 256 x 320:
+    // 195 -> 204 us) and stays an A/B.  impl + 1024 swaps the two forms (tests, tools/bench_split.py).
+    else if (NT == 4 && NP == 2 && (dasr_get_conv_bf16_impl() & 1024) == 0)
+        DASR_LAUNCH((k_conv3x3_split<4, 2, 2, 2>), grid, dim3(SP_NTHR), lds, stream, a);
+    else if (NT == 2 && NP == 2 && (dasr_get_conv_bf16_impl() & 1024) != 0)
+        DASR_LAUNCH((k_conv3x3_split<2, 2, 2, 2>), grid, dim3(SP_NTHR), lds, stream, a);
     else if (NT == 4) DASR_LAUNCH((k_conv3x3_split<4, NP>), grid, dim3(SP_NTHR), lds, stream, a);
     else if (chunk2)  DASR_LAUNCH((k_conv3x3_split_n32<2, 2>), grid, dim3(SP_NTHR), lds, stream, a);
     else if (NT == 2) DASR_LAUNCH((k_conv3x3_split<2, NP>), grid, dim3(SP_NTHR), lds, stream, a);

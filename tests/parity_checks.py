@@ -1481,12 +1481,15 @@ def check_split_conv(device, seed=5, pieces=3):
     # (impl + 64: the first fp16 x 2 weight-gradient kernel - operands split per K-step - for every block shape; GPU only)
     # impl + 256 + 512: the alternative forms of the forward / dgrad kernel - four waves with four tile rows each at 128
     # produced channels, one barrier per chunk at 64
-    for mode in (0, 2) + ((64, 256 + 512, 258 + 512) if pieces == 2 and device != "cpu" else ((256 + 512,) if pieces == 2 else ())):
+    # impl + 1024: swaps the two eight-wave forms - kernel-row K-steps at 128 produced channels (default there: 4 row groups x 2
+    # channel halves, kernel-column K-steps), the halves form at 64
+    for mode in (0, 2) + ((64, 768, 770, 1024, 1026) if pieces == 2 and device != "cpu" else ((768, 1024) if pieces == 2 else ())):
         one_wg = mode
         ops.set_conv_bf16_impl(mode)
         shapes = [(64, 64, 1, 17, 35), (128, 128, 1, 16, 32), (128, 64, 2, 33, 40), (64, 256, 1, 9, 70)]
         if device == "cpu":           # the emulator runs ~50 M MAC/s: a subset that still covers every code path
-            shapes = {0: [(64, 64, 1, 17, 35), (128, 128, 1, 9, 20)], 2: [(64, 128, 2, 17, 33)], 768: [(64, 128, 2, 17, 33), (64, 64, 1, 17, 35)]}[mode]
+            shapes = {0: [(64, 64, 1, 17, 35), (128, 128, 1, 9, 20)], 2: [(64, 128, 2, 17, 33)], 768: [(64, 128, 2, 17, 33), (64, 64, 1, 17, 35)],
+                      1024: [(64, 128, 2, 17, 33), (64, 64, 1, 17, 35)]}[mode]
         try:
             for (cin, cout, B, H, W) in shapes:
                 x = rn(B, cin, H, W) * (1.0 + rn(B, cin, 1, 1).abs()) * sx_
@@ -1526,7 +1529,7 @@ def check_split_conv(device, seed=5, pieces=3):
                 want = nhwc(gx64) + base.double()
                 g_acc = (accd.cpu().double() - want).abs().max().item() / want.abs().max().item()
                 assert g_acc <= fac * g_32 + 2 * slack, ("dgrad accumulate", cin, cout, g_acc)
-                out["%d->%d %dx%d%s" % (cin, cout, H, W, {0: "", 2: " 1wg", 64: " wgrad-v1", 128: " wgrad-v2", 768: " alt forms", 770: " alt forms 1wg"}[mode])] = tuple(
+                out["%d->%d %dx%d%s" % (cin, cout, H, W, {0: "", 2: " 1wg", 64: " wgrad-v1", 128: " wgrad-v2", 768: " alt forms", 770: " alt forms 1wg", 1024: " swapped forms", 1026: " swapped forms 1wg"}[mode])] = tuple(
                     float("%.3g" % v) for v in (e_sp, e_32, g_sp, g_32, g_acc, w_sp, w_32))
             # fused epilogues and the 32-channel tile (the HR tail: classic blocks, upscale convs): act, residual, PixelShuffle(2)
             eshapes = [(32, 32, 1, True, 1, 1, 17, 35), (64, 32, 2, False, 1, 2, 9, 40), (32, 128, 2, False, 2, 1, 10, 33),
@@ -1535,7 +1538,7 @@ def check_split_conv(device, seed=5, pieces=3):
                 eshapes = eshapes[:2] if mode == 0 else eshapes[2:3]
             if mode == 64:
                 eshapes = eshapes[:3]
-            if mode in (768, 770):
+            if mode in (768, 770, 1024, 1026):
                 eshapes = eshapes[2:] if device != "cpu" else eshapes[2:3]
             for (cin, cout, act, res, ps, B, H, W) in eshapes:
                 x = rn(B, cin, H, W)
@@ -1574,7 +1577,7 @@ def check_split_conv(device, seed=5, pieces=3):
                 w_sp, w_32 = rel_max(dw_sp.permute(3, 2, 0, 1), gw64), rel_max(dw_32.permute(3, 2, 0, 1), gw64)
                 assert w_sp <= fac * w_32 + slack, ("wgrad small block", cin, cout, w_sp, w_32)
                 assert rel_max(db_sp, dy.double().sum((0, 2, 3))) <= 2e-6
-                out["%d->%d act%d res%d ps%d%s" % (cin, cout, act, res, ps, {0: "", 2: " 1wg", 64: " wgrad-v1", 128: " wgrad-v2", 768: " alt forms", 770: " alt forms 1wg"}[mode])] = (
+                out["%d->%d act%d res%d ps%d%s" % (cin, cout, act, res, ps, {0: "", 2: " 1wg", 64: " wgrad-v1", 128: " wgrad-v2", 768: " alt forms", 770: " alt forms 1wg", 1024: " swapped forms", 1026: " swapped forms 1wg"}[mode])] = (
                     float("%.3g" % e_sp), float("%.3g" % e_32), float("%.3g" % g_sp))
         finally:
             ops.set_conv_bf16_impl(0)

@@ -39,7 +39,7 @@ def main():
         xm, ym = ops.absmax(x), ops.absmax(y)
         fl = 2.0 * 9 * ci * co * B * H * W
         keys = ("f32 fwd", "bf16x3 fwd", "fp16x2 fwd", "f32 dgrad", "bf16x3 dgrad", "fp16x2 dgrad", "f32 wgrad", "bf16x3 wgrad",
-                "fp16x2 wgrad", "fp16x2v1 wgrad", "fp16x2alt fwd", "fp16x2alt dgrad", "bf16x3 weights", "fp16x2 weights", "absmax x", "absmax y")
+                "fp16x2 wgrad", "fp16x2v1 wgrad", "fp16x2alt fwd", "fp16x2alt dgrad", "fp16x2h fwd", "fp16x2h dgrad", "bf16x3 weights", "fp16x2 weights", "absmax x", "absmax y")
         r = {k: [] for k in keys}
         for _ in range(3):
             r["f32 fwd"].append(timeit(lambda: ops.conv2d_fwd(x, wp, bias)))
@@ -54,6 +54,9 @@ def main():
             ops.set_conv_bf16_impl(256 + 512)   # the four-wave form (128 produced channels) / the chunk form (64) of the fp16 x 2 kernel
             r["fp16x2alt fwd"].append(timeit(lambda: ops.conv3x3_fwd_split2(x, xm, ws2, bias, co)))
             r["fp16x2alt dgrad"].append(timeit(lambda: ops.conv3x3_dgrad_split2(y, ym, ws2, x.shape)))
+            ops.set_conv_bf16_impl(1024)        # the other eight-wave form (128 produced channels: kernel-row steps; 64: channel halves)
+            r["fp16x2h fwd"].append(timeit(lambda: ops.conv3x3_fwd_split2(x, xm, ws2, bias, co)))
+            r["fp16x2h dgrad"].append(timeit(lambda: ops.conv3x3_dgrad_split2(y, ym, ws2, x.shape)))
             ops.set_conv_bf16_impl(64)      # the first fp16 x 2 weight-gradient kernel (operands split per K-step)
             r["fp16x2v1 wgrad"].append(timeit(lambda: ops.conv3x3_wgrad_split2(x, xm, y, ym)))
             ops.set_conv_bf16_impl(0)
