@@ -24,8 +24,8 @@ sys.path.insert(0, ROOT)
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)     # (a step is 35-150 ms: the defaults finish in seconds; the CPU baseline is
+    ap.add_argument("--warmup", type=int, default=3)     #  what takes the minute)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json config (default c2 = configs[1])")
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: c2 16, c3 32, c4 16, c5 1)")
     ap.add_argument("--mode", default="train", choices=("train", "infer"),
