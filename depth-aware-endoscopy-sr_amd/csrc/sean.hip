@@ -640,6 +640,148 @@ __global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_f
     if (AMAX) dasr_amax_commit(amax, om, sD, dasr_flat_wg(), dasr_flat_nwg());     // (sD: dead after the last tile)
 }
 
+// ---- forward, one-hot, bf16 activations with EIGHT channels (16 bytes) per lane --------------------------------------
+// With 4 bf16 channels per lane a wave instruction moves 512 bytes, half of what the fp32 instantiation has in flight per
+// instruction - the bf16 forward sat at 0.57-0.66 of the HBM peak against 0.75-0.8.  Here a lane owns 8 channels of one pixel
+// (one 16-byte load per operand, one 16-byte store), a wave instruction covers 8 pixels x 64 channels = 1 KB, and the
+// structure is otherwise that of k_sean_fwd_onehot (groups of 8 pixels, two register buffers, persistent tiles).  The gather
+// reads the pixel's nine region bytes once and two float4 per tap and table (channels 8 c8 .. + 3 and + 4 .. + 7): lanes of
+// DIFFERENT pixels now share a 16-lane LDS pass, a 2-way conflict only where the two pixels lie in different regions.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 ld8_nt(const bf16_t* p) {
+    const s16x8 r = __builtin_nontemporal_load((const s16x8*)p);
+    bf16x8 v;
+    __builtin_memcpy(&v, &r, 16);
+    return v;
+}
+__device__ __forceinline__ bf16x8 ld8(const bf16_t* p) { return *(const bf16x8*)p; }
+template <bool RELU, bool HAS_RES>
+__global__ void __launch_bounds__(256, HAS_RES ? DASR_SEAN_RES_OCC : 3) k_sean_fwd_onehot_w8(SeanGeom g, const bf16_t* __restrict__ t,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ var,
+                                                            const bf16_t* __restrict__ gb2,
+                                                            const unsigned char* __restrict__ region,
+                                                            const int* __restrict__ flag, const float* __restrict__ D,
+                                                            const float* __restrict__ bias_g,
+                                                            const float* __restrict__ bias_b,
+                                                            const float* __restrict__ alpha_g,
+                                                            const float* __restrict__ alpha_b,
+                                                            const bf16_t* __restrict__ residual,
+                                                            bf16_t* __restrict__ out, float eps, int tiles_per_wg) {
+    DASR_DYN_SMEM(smem);
+    constexpr int TH = SF_TH, NG = TH;                         // NG groups of 8 pixels per wave and tile (TH/4 rows x 4)
+    const int K1 = g.K + 1;
+    float* sD = (float*)smem;                                  // [18][K+1][64]
+    unsigned char* sR = (unsigned char*)(sD + 18 * K1 * 64);   // [(TH+2)*(TW+2)]
+    const int tiles_x = (g.W + SF_TW - 1) / SF_TW, tiles_y = (g.H + TH - 1) / TH;
+    const int tiles_per_sample = tiles_x * tiles_y;
+    const int c0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, wv = DASR_UNIFORM((int)(threadIdx.x >> 6));
+    const int c8 = lane & 7, ps = lane >> 3;
+    const bool live = c0 + 8 * c8 < g.C;
+    const int c = live ? c0 + 8 * c8 : 0;                      // dead lanes (C % 64 != 0) shadow channel 0, never store
+    const int base = tiles_per_wg >> 16, rem = tiles_per_wg & 0xffff;          // (as k_sean_fwd_onehot)
+    const int first = blockIdx.x * base + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    int last = first + base + ((int)blockIdx.x < rem ? 1 : 0);
+    if (last > g.B * tiles_per_sample) last = g.B * tiles_per_sample;
+    if (first >= last) return;
+    auto tile_of = [&](int tt) {
+        const int tile = tt % tiles_per_sample;
+        return SeanTile{tt / tiles_per_sample, (tile / tiles_x) * TH, (tile % tiles_x) * SF_TW};
+    };
+    struct Buf { bf16x8 tv, g2, b2, rv; };
+    auto issue = [&](const SeanTile& T, int grp, Buf& f) {
+        const int y = imin(T.y0 + wv + 4 * (grp >> 2), g.H - 1);                // wave-uniform
+        const size_t row = ((size_t)T.b * g.H + y) * g.W;                       // scalar
+        const char* trow = (const char*)(t + row * g.C);
+        const char* grow = (const char*)(gb2 + row * 2 * g.C);
+        const char* brow = grow + (size_t)g.C * sizeof(bf16_t);                  // beta half of the (gamma2 | beta2) pair
+        const char* rrow = HAS_RES ? (const char*)(residual + row * g.C) : nullptr;
+        const unsigned x = (unsigned)imin(T.x0 + 8 * (grp & 3) + ps, g.W - 1);
+        const unsigned ot = (x * (unsigned)g.C + (unsigned)c) * 2u;
+        const unsigned og = (x * 2u * (unsigned)g.C + (unsigned)c) * 2u;
+        f.tv = ld8_nt((const bf16_t*)(trow + ot));                               // streamed once: keep D / halos cached
+        f.g2 = ld8_nt((const bf16_t*)(grow + og));
+        f.b2 = ld8_nt((const bf16_t*)(brow + og));
+        if (HAS_RES) f.rv = ld8((const bf16_t*)(rrow + ot));
+    };
+    Buf fa, fb;
+    SeanTile T = tile_of(first);
+    issue(T, 0, fa);
+    if (flag && *flag != 0) return;   // masks are not one-hot: the general kernel does the work
+    const float a_g = alpha_g[0], a_b = alpha_b[0];
+    int cur_b = -1;
+    float mu[8], sc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mu[j] = 0.f; sc[j] = 0.f; }
+    for (int tt = first; tt < last; ++tt) {
+        const int b = T.b, y0 = T.y0, x0 = T.x0;
+        __syncthreads();                                   // previous tile is done with sR (and sD)
+        if (b != cur_b) {
+            sean_stage_D<HAS_RES ? 2 : 4>(g, D, sD, b, c0, bias_g, bias_b);
+            cur_b = b;
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    mu[j] = mean[(size_t)b * g.C + c + j];
+                    sc[j] = dasr_double_in_scale(var[(size_t)b * g.C + c + j], eps);
+                }
+            }
+        }
+        sean_stage_R(g, region, sR, b, y0, x0, TH);
+        __syncthreads();
+        auto consume = [&](int grp, const Buf& f) {
+            const int ly = wv + 4 * (grp >> 2), y = y0 + ly;
+            const size_t row = ((size_t)b * g.H + imin(y, g.H - 1)) * g.W;
+            char* orow = (char*)(out + row * g.C);
+            const int lx = 8 * (grp & 3) + ps, x = x0 + lx;
+            int k[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) k[tap] = sR[(ly + tap / 3) * (SF_TW + 2) + lx + tap % 3];
+            bf16x8 o8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cq = 2 * c8 + h;
+                float4 g1 = *(const float4*)(sD + ((0 * 9 + 0) * K1 + k[0]) * 64 + 4 * cq);
+#pragma unroll
+                for (int tap = 1; tap < 9; ++tap) g1 = f4add(g1, *(const float4*)(sD + ((0 * 9 + tap) * K1 + k[tap]) * 64 + 4 * cq));
+                float4 b1 = *(const float4*)(sD + ((1 * 9 + 0) * K1 + k[0]) * 64 + 4 * cq);
+#pragma unroll
+                for (int tap = 1; tap < 9; ++tap) b1 = f4add(b1, *(const float4*)(sD + ((1 * 9 + tap) * K1 + k[tap]) * 64 + 4 * cq));
+                const float g1v[4] = {g1.x, g1.y, g1.z, g1.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * h + j;
+                    float o = (dasr_bf2f(f.tv[e]) - mu[e]) * sc[e] * (1.f + a_g * g1v[j] + (1.f - a_g) * dasr_bf2f(f.g2[e])) +
+                              a_b * b1v[j] + (1.f - a_b) * dasr_bf2f(f.b2[e]);
+                    if (HAS_RES) o += dasr_bf2f(f.rv[e]);
+                    if (RELU) o = o > 0.f ? o : 0.f;
+                    o8[e] = dasr_f2bf(o);
+                }
+            }
+            if (live && y < g.H && x < g.W) {
+                s16x8 r;
+                __builtin_memcpy(&r, &o8, 16);
+                __builtin_nontemporal_store(r, (s16x8*)(orow + ((unsigned)x * (unsigned)g.C + (unsigned)c) * 2u));
+            }
+        };
+#pragma unroll 1
+        for (int grp = 0; grp < NG - 2; grp += 2) {
+            issue(T, grp + 1, fb);
+            consume(grp, fa);
+            issue(T, grp + 2, fa);
+            consume(grp + 1, fb);
+        }
+        issue(T, NG - 1, fb);
+        consume(NG - 2, fa);
+        if (tt + 1 < last) {
+            T = tile_of(tt + 1);
+            issue(T, 0, fa);
+        }
+        consume(NG - 1, fb);
+    }
+}
+
 // ---- backward, pass A, one-hot -------------------------------------------------------------------------
 // The dynamic-kernel gradient  dD[s][tap][k][c] = sum_p [r(p+tap) == k] * G_s[p][c],  G = (a_g*dgamma, a_b*dbeta),
 // is a segmented reduction by region.  LDS float atomics are far too slow for it on gfx950 (measured ~3 cycles
@@ -1067,9 +1209,15 @@ static int sean_fwd_impl(const T* t, const float* mean, const float* var, const 
         if (nwg > tiles) nwg = tiles;
         const int per = ((tiles / nwg) << 16) | (tiles % nwg);      // (base, rem), see the kernel; rem < nwg <= 768
         size_t lds = sizeof(float) * (size_t)(18 * (K + 1) * 64) + (SF_TH + 2) * (SF_TW + 2);
+        // bf16 activations: eight channels per lane (C % 8 == 0); dasr_set_conv_bf16_impl(+ 2048): the 4-channel form (A/B, tests)
+        const bool w8 = sizeof(T) == 2 && (C % 8) == 0 && (dasr_get_conv_bf16_impl() & 2048) == 0;
 #define SEAN_FWD_GO(RELU, RES)                                                                                     \
     do {                                                                                                           \
-        if (fused_amax)                                                                                            \
+        if (w8)                                                                                                    \
+            DASR_LAUNCH((k_sean_fwd_onehot_w8<RELU, RES>), dim3(nwg, slices), dim3(256), lds, stream, g, (const bf16_t*)t, \
+                        mean, var, (const bf16_t*)gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b,      \
+                        (const bf16_t*)residual, (bf16_t*)out, eps, per);                                            \
+        else if (fused_amax)                                                                                            \
             DASR_LAUNCH((k_sean_fwd_onehot<RELU, RES, T, sizeof(T) == 4>), dim3(nwg, slices), dim3(256), lds, stream, g, t, \
                         mean, var, gb2, region, onehot_flag, D, bias_g, bias_b, alpha_g, alpha_b, residual, out, eps, per, out_amax); \
         else                                                                                                       \

@@ -96,6 +96,8 @@ class Prepack:
         self.ready = False
         self.entries = {}
         self.tables = None
+        self.misses = 0             # tables built and then found stale: parameters that move every step (nn.DataParallel
+        self.off = False            # replicas are fresh copies) make the recording pointless - two in a row turn it off
 
     @staticmethod
     def signature(inp, act_dtype):
@@ -109,7 +111,11 @@ class Prepack:
             ops.weight_pack_multi(self.tables[0])
             if self.tables[1] is not None:
                 ops.conv3x3_split2_weights_multi(self.tables[1])
+            self.misses = 0
             return
+        if self.ready and sig == self.sig:
+            self.misses += 1
+            self.off = self.off or self.misses >= 2
         self.sig, self.ready, self.entries, self.tables = sig, False, {}, None
 
     def get(self, key):
@@ -117,7 +123,7 @@ class Prepack:
 
     def note(self, key, jobs, w, inv=None):
         """Recording: ``jobs`` = [(v Var, g Var or None, transposed, o_off, plain)] that fill the buffer ``w``."""
-        if not self.ready and key is not None:
+        if not self.ready and not self.off and key is not None:
             self.entries[key] = {"jobs": jobs, "w": w, "inv": inv, "split": None}
 
     def note_split(self, key, split):

@@ -377,7 +377,10 @@ int dasr_conv2d_epilogue_bwd_bf16(const unsigned short* dy, const unsigned short
  * 2 = the persistent kernel with one workgroup per XCD (tests: long per-workgroup item lists on small shapes);
  * + 16 = force its 8-row / 4-wave form, + 32 = its 16-row / 8-wave form (default: by problem size);
  * + 64 = the fp16 x 2 split weight gradient on its first kernel (operands split per K-step; default: split at staging);
- * + 256 = the fp16 x 2 split forward / dgrad at 128 produced channels in its four-wave form (four tile rows per wave).
+ * + 256 = the fp16 x 2 split forward / dgrad at 128 produced channels in its four-wave form (four tile rows per wave);
+ * + 512 = ... at 64 produced channels with all nine kernel slices of a chunk per barrier; + 1024 = swap its two eight-wave
+ * forms (128 produced channels: kernel-row K-steps instead of channel halves x kernel columns; 64: the reverse);
+ * + 2048 = the bf16 dynamic-conv forward (dasr_sean_fwd_bf16) with 4 instead of 8 channels per lane.
  * For A/B measurements and tests; process-wide, not thread-safe against concurrent launches.
  * dasr_conv_bf16_v2_launches(): how many times the persistent kernel has been launched by this process. */
 int dasr_set_conv_bf16_impl(int impl);

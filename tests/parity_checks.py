@@ -1911,6 +1911,12 @@ def check_bf16_ops_vs_fp32_kernels(device, seed=1):
                    h(r) if r is not None else None, True)
             y32, y16 = ops.sean_fwd(*a32), ops.sean_fwd(*a16)
             assert y16.dtype == BF16 and torch.equal(y16, y32.to(BF16)), ("sean fwd", soft, r is not None)
+            ops.set_conv_bf16_impl(2048)            # the 4-channels-per-lane form of the bf16 gather kernel (default: 8)
+            try:
+                y16b = ops.sean_fwd(*a16)
+            finally:
+                ops.set_conv_bf16_impl(0)
+            assert torch.equal(y16b, y16), ("sean fwd, 4 channels per lane", soft, r is not None)
         # backward on the bf16-valued forward output
         y = y16.float()
         g32 = ops.sean_bwd(dev(dout), y, dev(t), mean, var, dev(gb2), mask, region, flag, dev(D), dev(bg), dev(bb), dev(ag),

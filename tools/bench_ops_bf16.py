@@ -52,10 +52,13 @@ def main():
         us = timeit(lambda: ops.instnorm_stats(t), a.iters)
         print("instnorm_stats bf16       %8.1f us  %7.1f GB/s" % (us, px * C * 2 / us / 1e3))
         mean, var = ops.instnorm_stats(t)
-        for name, r in (("sean_fwd bf16", None), ("sean_fwd bf16 +res", resid)):
-            us = timeit(lambda: ops.sean_fwd(t, mean, var, gb2, mk, region, None, D, bg, bb, ag, ab, r, True), a.iters)
-            nbytes = px * (2 * (4 * C + (C if r is not None else 0)) + 1)
-            print("%-25s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)" % (name, us, nbytes / us / 1e3, nbytes / us / 1e3 / 80))
+        for impl, tag in ((0, ""), (2048, " 4ch/lane")):        # default: 8 channels (16 bytes) per lane; + 2048: the first form
+            ops.set_conv_bf16_impl(impl)
+            for name, r in (("sean_fwd bf16", None), ("sean_fwd bf16 +res", resid)):
+                us = timeit(lambda: ops.sean_fwd(t, mean, var, gb2, mk, region, None, D, bg, bb, ag, ab, r, True), a.iters)
+                nbytes = px * (2 * (4 * C + (C if r is not None else 0)) + 1)
+                print("%-25s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)" % (name + tag, us, nbytes / us / 1e3, nbytes / us / 1e3 / 80))
+        ops.set_conv_bf16_impl(0)
         out = ops.sean_fwd(t, mean, var, gb2, mk, region, None, D, bg, bb, ag, ab, resid, True)
         dout = rb(B, H, W, C)
         us = timeit(lambda: ops.sean_bwd(dout, out, t, mean, var, gb2, mk, region, None, D, bg, bb, ag, ab, True, True),
