@@ -98,6 +98,13 @@ class Prepack:
         self.tables = None
         self.misses = 0             # tables built and then found stale: parameters that move every step (nn.DataParallel
         self.off = False            # replicas are fresh copies) make the recording pointless - two in a row turn it off
+        self.lock = _threading.Lock()   # one forward at a time (replicas on one device run in threads: the others go per tensor)
+
+    def __deepcopy__(self, memo):       # a copied / pickled module starts with an empty recording (device buffers and the
+        return Prepack()                # lock do not travel)
+
+    def __reduce__(self):
+        return (Prepack, ())
 
     @staticmethod
     def signature(inp, act_dtype):
@@ -851,14 +858,25 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=No
     """DepthNet.forward (sftmd_arch.py:912-950). ``inp`` [B,3,H,W], ``depth_map`` [B,1,h,w],
     ``depth_mask`` [B,K,h,w] are the caller's NCHW tensors; returns (out NCHW tensor, out Var).
     ``region``: the masks' region bytes [B,h,w] when they were prepared on the device (prep.depth_to_masks)."""
+    pp = tape.prepack
+    if pp is not None and not (PREPACK and tape.enabled and pp.lock.acquire(blocking=False)):
+        pp = tape.prepack = None
+    try:
+        if pp is not None:
+            pp.begin(P, Prepack.signature(inp, tape.act_dtype))
+        out = _depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region)
+        if pp is not None:
+            pp.finish()
+        return out
+    finally:
+        if pp is not None:
+            pp.lock.release()
+
+
+def _depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region):
     plan = block_plan(cfg)
     nb, scale = cfg["nb"], cfg["scale"]
     B = inp.shape[0]
-    if tape.prepack is not None:
-        if PREPACK and tape.enabled:
-            tape.prepack.begin(P, Prepack.signature(inp, tape.act_dtype))
-        else:
-            tape.prepack = None
     x0 = Var(ops.nchw_to_nhwc(inp))
     dm = Var(depth_map.reshape(B, depth_map.shape[2], depth_map.shape[3], 1))   # [B,1,h,w] == [B,h,w,1]
     L = ops.ACT_LRELU
@@ -928,8 +946,6 @@ def depthnet_forward(tape, P, cfg, consts, inp, depth_map, depth_mask, region=No
     y = conv(tape, fea, pack(tape, P["conv_output.weight"]), P["conv_output.bias"], pad=4, side_wgrad=True)     # :948
     lo, hi = cfg["out_min"], cfg["out_max"]
     out = Var(ops.clamp_to_nchw(y.data, lo, hi), True)                                          # :950
-    if tape.prepack is not None:
-        tape.prepack.finish()
 
     def bwd():
         if out.grad is None:
