@@ -145,9 +145,28 @@ __global__ void __launch_bounds__(512) k_conv9_fwd_split(Conv9SplitArgs a) {
             vin[u] = dasr_buffer_load16(rx, off);
         }
     };
-    int tile = blockIdx.x;
-    if (tile < total) fetch(tile, 0);
-    for (; tile < total; tile += gridDim.x) {
+    // Which tile a (workgroup, trip) slot works on.  a.P == 0: slot s = tile s.  a.P == 1 (256 workgroups, dealt to the eight
+    // XCDs round robin): the 32 workgroups of an XCD take a 4 x 8 block of tiles per trip, so that the halo rows and columns a
+    // tile shares with its neighbours (16 x 64 input pixels per 8 x 56 outputs: 2.3 x the bytes) are re-read from that XCD's L2
+    // while they are hot instead of from another XCD's tile in flight at the same time.
+    const int nbx = (tiles_x + 7) / 8, nby = (tiles_y + 3) / 4;
+    const int nslots = a.P == 1 ? ((a.B * nbx * nby + 7) / 8) * 256 : total;
+    auto slot_tile = [&](int s) {
+        if (a.P != 1) return s;
+        const int xcd = s & 7, j = (s >> 3) & 31, g = (s >> 8) * 8 + xcd;
+        const int bimg = g / (nbx * nby), r = g - bimg * (nbx * nby);
+        const int ty = (r / nbx) * 4 + (j >> 3), tx = (r % nbx) * 8 + (j & 7);
+        return (bimg < a.B && ty < tiles_y && tx < tiles_x) ? (bimg * tiles_y + ty) * tiles_x + tx : -1;
+    };
+    auto next_slot = [&](int s) {                     // the next slot of this workgroup that holds a tile (or nslots)
+        for (s += gridDim.x; s < nslots && slot_tile(s) < 0; s += gridDim.x) {}
+        return s;
+    };
+    int slot = (int)blockIdx.x < nslots && slot_tile(blockIdx.x) >= 0 ? (int)blockIdx.x : next_slot(blockIdx.x);
+    if (slot < nslots) fetch(slot_tile(slot), 0);
+    for (; slot < nslots;) {
+        const int tile = slot_tile(slot);
+        const int nslot = next_slot(slot);
         const int b = tile / (tiles_x * tiles_y), tt = tile - b * (tiles_x * tiles_y);
         const int x0 = (tt % tiles_x) * TWO, y0 = (tt / tiles_x) * S9_TH;
         f32x16 acc[2];
@@ -175,7 +194,7 @@ __global__ void __launch_bounds__(512) k_conv9_fwd_split(Conv9SplitArgs a) {
             __syncthreads();
             {                                              // next chunk of this tile, or the first chunk of the next tile
                 const bool lastc = c + 1 == NCK;
-                const int nt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;
+                const int nt = nslot < nslots ? slot_tile(nslot) : tile;
                 fetch(lastc ? nt : tile, lastc ? 0 : 16 * (c + 1));
             }
             const int wo = c * 9 * 32 * S9F_ST;
@@ -214,6 +233,7 @@ __global__ void __launch_bounds__(512) k_conv9_fwd_split(Conv9SplitArgs a) {
             for (int kw = 0; kw < 9; ++kw) v += sP[(r * S9F_TQ + ox + kw) * S9F_PST + kw * a.Cout + co];
             y[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co] = fmaf(v, inv, a.bias ? a.bias[co] : 0.f);
         }
+        slot = nslot;
     }
 }
 
@@ -503,6 +523,7 @@ int conv9_split_fwd(const ConvGeom& g, const float* x, const float* xmax, const 
     const int tiles = ((g.W + TWO - 1) / TWO) * ((g.H + S9_TH - 1) / S9_TH) * g.B;
     const size_t lds = sizeof(h16_t) * (size_t)(2 * (S9_TH + 8) * S9F_TQ * S9F_ST + 2 * (g.Cin / 16) * 9 * 32 * S9F_ST) + 128;
     const int cap = (dasr_get_conv_bf16_impl() & 3) == 2 ? 3 : 256;    // (impl 2, tests: long per-workgroup tile lists)
+    a.P = (tiles >= 256 && cap == 256 && (dasr_get_conv_bf16_impl() & 4096) == 0) ? 1 : 0;      // XCD-blocked tile order (+ 4096: linear, A/B)
     DASR_LAUNCH(k_conv9_fwd_split, dim3(tiles < cap ? tiles : cap), dim3(512), lds, stream, a);     // one persistent workgroup per CU
     DASR_RETURN_LAUNCH_STATUS();
 }

@@ -87,7 +87,7 @@ __device__ __forceinline__ void v2_wait_vm() {
 #endif
 }
 
-// DBG: timing experiments only (wrong results), reachable through dasr_set_conv_bf16_impl(2 | flags << 12) when the library is
+// DBG: timing experiments only (wrong results), reachable through dasr_set_conv_bf16_impl(2 | flags << 13) when the library is
 // built with -DDASR_V2_DEBUG: 1 = no kernel-slice DMA in the loop, 2 = no halo DMA in the loop, 4 = no MFMA, 8 = no output
 // stores, 16 = no per-step wait / barrier, 32 = no operand LDS reads.
 // the same with the count as a value that constant-folds after unrolling (the tap loop's index is not a constant expression)
@@ -470,12 +470,12 @@ static int g_conv_bf16_impl = 0;
 static int g_conv_bf16_dbg = 0;
 static int g_conv_bf16_v2_launches = 0;
 extern "C" int dasr_set_conv_bf16_impl(int impl) {
-    const int dbg = impl >> 12;
-    impl &= 4095;
+    const int dbg = impl >> 13;
+    impl &= 8191;
 #ifndef DASR_V2_DEBUG
     if (dbg != 0) return DASR_E_UNSUPPORTED;
 #endif
-    if (impl < 0 || (impl & 3) > 2 || ((impl >> 4) & 3) > 2 || (impl & 12) || (impl >> 12)) return DASR_E_UNSUPPORTED;   // (+ 64 / + 128: see sw_launch, conv_split_bf16.hip)
+    if (impl < 0 || (impl & 3) > 2 || ((impl >> 4) & 3) > 2 || (impl & 12) || (impl >> 13)) return DASR_E_UNSUPPORTED;   // (+ 64 / + 128: see sw_launch, conv_split_bf16.hip)
     g_conv_bf16_impl = impl;
     g_conv_bf16_dbg = dbg;
     return DASR_OK;

@@ -380,7 +380,8 @@ int dasr_conv2d_epilogue_bwd_bf16(const unsigned short* dy, const unsigned short
  * + 256 = the fp16 x 2 split forward / dgrad at 128 produced channels in its four-wave form (four tile rows per wave);
  * + 512 = ... at 64 produced channels with all nine kernel slices of a chunk per barrier; + 1024 = swap its two eight-wave
  * forms (128 produced channels: kernel-row K-steps instead of channel halves x kernel columns; 64: the reverse);
- * + 2048 = the bf16 dynamic-conv forward (dasr_sean_fwd_bf16) with 4 instead of 8 channels per lane.
+ * + 2048 = the bf16 dynamic-conv forward (dasr_sean_fwd_bf16) with 4 instead of 8 channels per lane;
+ * + 4096 = the 9x9 split forward with the linear instead of the XCD-blocked tile order.
  * For A/B measurements and tests; process-wide, not thread-safe against concurrent launches.
  * dasr_conv_bf16_v2_launches(): how many times the persistent kernel has been launched by this process. */
 int dasr_set_conv_bf16_impl(int impl);

@@ -1220,6 +1220,20 @@ def check_conv9_split(device, seed=9):
             assert w_sp <= fac * w_32 + slack, ("conv9 wgrad", B, H, W, cout, w_sp, w_32)
             assert rel_max(db_sp, dy.double().sum((0, 2, 3))) <= 2 * rel_max(db_32, dy.double().sum((0, 2, 3))) + 1e-6
             out["%dx%dx%d co%d impl%d" % (B, H, W, cout, impl)] = tuple(float("%.3g" % v) for v in (e_sp, e_32, g_sp, g_32, g_acc, w_sp, w_32))
+        # >= 256 tiles: the forward deals its tiles to the XCDs in 4 x 8 blocks (ragged blocks in both directions here, and more
+        # blocks than one trip holds) - bit-identical to the linear tile order (impl + 4096), which the cases above ran
+        B, H, W, cout = 3, 76, 500, 3
+        x = (rn(B, H, W, 32) * 1.7).to(device)
+        wp = ops.pack_hwio((rn(9, 9, 32, cout) * 0.02).to(device))
+        bd = (rn(cout) * 0.3).to(device)
+        wm, xm = ops.absmax(wp[0]), ops.absmax(x)
+        y_blocked = ops.conv9_fwd_split2(x, xm, wp, wm, bd)
+        ops.set_conv_bf16_impl(4096)
+        y_linear = ops.conv9_fwd_split2(x, xm, wp, wm, bd)
+        assert torch.equal(y_blocked, y_linear), "conv9 fwd: XCD-blocked tile order differs from the linear one"
+        y_32 = ops.conv2d_fwd(x, wp, bd, pad=4)
+        assert rel_max(y_blocked, y_32.double()) <= 1e-5
+        out["blocked tile order"] = "bit-identical to linear (%d tiles)" % (B * ((H + 7) // 8) * ((W + 55) // 56))
     finally:
         ops.set_conv_bf16_impl(0)
     return out

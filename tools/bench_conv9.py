@@ -33,10 +33,18 @@ def main():
     dy = torch.randn(B, H, W, co, device=dev)
     wm, xm, dm = ops.absmax(wp[0]), ops.absmax(x), ops.absmax(dy)
     fl = 2.0 * 81 * ci * co * B * H * W
+
+    def lin(fn):        # the same launch with the linear tile order (default: 4 x 8 tile blocks per XCD)
+        ops.set_conv_bf16_impl(4096)
+        try:
+            return fn()
+        finally:
+            ops.set_conv_bf16_impl(0)
     r = {}
     for _ in range(3):
         for k, fn in (("f32 fwd", lambda: ops.conv2d_fwd(x, wp, bias, pad=4)),
                       ("fp16x2 fwd", lambda: ops.conv9_fwd_split2(x, xm, wp, wm, bias)),
+                      ("fp16x2 fwd linear", lambda: lin(lambda: ops.conv9_fwd_split2(x, xm, wp, wm, bias))),
                       ("f32 dgrad", lambda: ops.conv2d_dgrad(dy, wp, x.shape, pad=4)),
                       ("fp16x2 dgrad", lambda: ops.conv9_dgrad_split2(dy, dm, wp, wm, x.shape)),
                       ("f32 wgrad", lambda: ops.conv2d_wgrad(x, dy, (9, 9, ci, co), pad=4)),
@@ -45,7 +53,7 @@ def main():
             r.setdefault(k, []).append(timeit(fn))
     for k, v in r.items():
         us = sorted(v)[1]
-        print("B=%d 9x9 32->3 @%dx%d %-14s %9.1f us  %6.1f TF (useful fp32-equivalent)" % (B, H, W, k, us, fl / us / 1e6))
+        print("B=%d 9x9 32->3 @%dx%d %-18s %9.1f us  %6.1f TF (useful fp32-equivalent)" % (B, H, W, k, us, fl / us / 1e6))
 
 
 if __name__ == "__main__":

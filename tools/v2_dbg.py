@@ -40,7 +40,7 @@ def main():
         fl = 2.0 * 9 * ci * co * B * H * W
         for rnd in range(2):
             for dbg in sorted(NAMES):
-                ops.set_conv_bf16_impl(form | (dbg << 12))
+                ops.set_conv_bf16_impl(form | (dbg << 13))
                 us = timeit(lambda: ops.conv2d_fwd(x, wt, bias))
                 if rnd == 1:
                     print("form %d %3d->%3d %-24s %8.1f us  %7.1f TF-equivalent" % (form, ci, co, NAMES[dbg], us, fl / us / 1e6))
