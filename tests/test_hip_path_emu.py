@@ -39,7 +39,7 @@ def test_prepack_ops(emu):
 
 
 def test_prepack_net(emu):
-    print(pc.check_prepack_net("cpu", "x2_nb4", steps=2))
+    print(pc.check_prepack_net("cpu", "x2_one_depth_block", steps=2))
 
 
 def test_pixel_shuffle_bit_exact(emu):
