@@ -1,6 +1,6 @@
 """Root conftest: the CPU suite (`pytest tests -m "not gpu"`) spends its time in the CPU kernel emulator, one core per
-test; when pytest-xdist is importable and the caller did not choose a worker count, it is spread over four workers
-(9.4 min serial -> under 4 min).  GPU runs (`-m gpu`) are never touched: they stay in ONE process.  DASR_TESTS_SERIAL=1
+test; when pytest-xdist is importable and the caller did not choose a worker count, it is spread over six workers
+(~35 min serial -> ~7 min on the build container's 8 cores).  GPU runs (`-m gpu`) are never touched: they stay in ONE process.  DASR_TESTS_SERIAL=1
 keeps the CPU suite serial too."""
 import os
 
@@ -18,7 +18,7 @@ def pytest_cmdline_main(config):
         return None
     if getattr(opt, "collectonly", False):
         return None
-    opt.numprocesses = 4
+    opt.numprocesses = 6
     opt.dist = "load"
-    opt.tx = ["popen"] * 4
+    opt.tx = ["popen"] * 6
     return None

@@ -1498,7 +1498,7 @@ def check_split_conv(device, seed=5, pieces=3):
     # produced channels, one barrier per chunk at 64
     # impl + 1024: swaps the two eight-wave forms - kernel-row K-steps at 128 produced channels (default there: 4 row groups x 2
     # channel halves, kernel-column K-steps), the halves form at 64
-    for mode in (0, 2) + ((64, 768, 770, 1024, 1026) if pieces == 2 and device != "cpu" else ((768, 1024) if pieces == 2 else ())):
+    for mode in (0, 2) + ((64, 768, 770, 1024, 1026) if pieces == 2 and device != "cpu" else ((1024,) if pieces == 2 else ())):
         one_wg = mode
         ops.set_conv_bf16_impl(mode)
         shapes = [(64, 64, 1, 17, 35), (128, 128, 1, 16, 32), (128, 64, 2, 33, 40), (64, 256, 1, 9, 70)]
