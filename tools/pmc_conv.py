@@ -18,10 +18,21 @@ for spec in sys.argv[2:]:
             k = r["Kernel_Name"].split("(")[0]
             if "conv3x3" in k:
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = collections.defaultdict(list)                 # kernel durations of the same run (the --kernel-trace CSV)
+    for path in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            k = r["Kernel_Name"].split("(")[0]
+            if "conv3x3" in k:
+                dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     run = {}
     for k, ctrs in agg.items():
         c = {n: sum(v) / len(v) for n, v in ctrs.items()}
         d_ = dict(c)
+        if dur.get(k):
+            d_["avg_duration_us"] = round(sum(dur[k]) / len(dur[k]) / 1e3, 2)
+            if c.get("SQ_BUSY_CU_CYCLES"):
+                # every CU is busy for the whole launch of these persistent kernels: busy cycles per CU / duration = shader clock
+                d_["shader_clock_ghz_from_busy_cycles"] = round(c["SQ_BUSY_CU_CYCLES"] / 256 / (sum(dur[k]) / len(dur[k])), 3)
         if c.get("SQ_BUSY_CU_CYCLES") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
             d_["mfma_busy_share_of_cu_busy"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CU_CYCLES"] / 4, 4)
         if c.get("SQ_INSTS_MFMA") and c.get("SQ_INSTS_VALU"):
