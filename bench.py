@@ -369,6 +369,7 @@ def main():
         sys.exit(self_launch(args))
 
     global torch, dist, harness, networks, ops, prep, synth
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # (dmabuf IPC: RCCL between ranks needs it on this driver; before HIP starts)
     import torch
     import torch.distributed as dist
     cpu = args.device == "cpu"
